@@ -1,0 +1,257 @@
+"""Read side of the spectral line database (SQLite file written by pyLBL).
+
+Mirrors what the lines path needs from pyLBL/database.py: ``Database.path``
+(:146), ``.molecules()`` (:340-348), ``.gas(name)`` (:350-367) and ``.tips(name)``
+(:369-395).  Ingest from HITRAN/TIPS web services (``create``) is out of scope.
+
+The file is read with the standard-library ``sqlite3`` using the same four SELECT
+statements the reference's C engine issues, so rows come back in the same
+(rowid) order the reference iterates them in:
+
+* alias -> molecule id      pyLBL/c_lib/spectral_database.c:143
+* TIPS rows                  pyLBL/c_lib/spectral_database.c:55
+* isotopologue masses        pyLBL/c_lib/spectral_database.c:113
+* transitions                pyLBL/c_lib/absorption.c:69-70
+
+``LineTable`` is the struct-of-arrays form one molecule is turned into, once, before
+it is uploaded to the GPU; it is also what the synthetic generators produce.
+"""
+from collections import namedtuple
+from dataclasses import dataclass
+import sqlite3
+
+import numpy as np
+
+from .errors import AliasNotFoundError, IsotopologuesNotFoundError, \
+                    TipsDataNotFoundError, TransitionsNotFoundError
+
+
+TIPS_REFERENCE_TEMPERATURE = 296.  # pyLBL/tips.py:6
+
+# The reference's C engine holds masses in a 32-slot buffer (absorption.c:62-64).
+MASS_SLOTS = 32
+
+LINE_COLUMNS = ("nu", "sw", "gamma_air", "gamma_self", "n_air", "elower", "delta_air")
+
+
+@dataclass
+class LineTable:
+    """One molecule's transitions (reference row order), masses and TIPS table."""
+    formula: str
+    molecule_id: int
+    nu: np.ndarray
+    sw: np.ndarray
+    gamma_air: np.ndarray
+    gamma_self: np.ndarray
+    n_air: np.ndarray
+    elower: np.ndarray
+    delta_air: np.ndarray
+    local_iso_id: np.ndarray     # int32, raw column value (0 means isotopologue 10)
+    isoid: np.ndarray            # int, one per isotopologue row
+    mass: np.ndarray             # float64, one per isotopologue row
+    tips_temperature: np.ndarray  # float64[num_t]
+    tips_data: np.ndarray        # float64[num_iso, num_t]
+
+    @property
+    def num_lines(self):
+        return int(self.nu.size)
+
+    def mass_by_slot(self):
+        """mass[isoid - 1], HITRAN isoid 0 stored as 10 (spectral_database.c:113-129)."""
+        out = np.zeros(MASS_SLOTS, dtype=np.float64)
+        for isoid, mass in zip(self.isoid, self.mass):
+            slot = 10 if int(isoid) == 0 else int(isoid)
+            if slot > MASS_SLOTS:
+                raise ValueError(f"isotopologue id {isoid} does not fit {MASS_SLOTS} slots.")
+            out[slot - 1] = mass
+        return out
+
+    def subset(self, mask):
+        """Same molecule, a subset of rows (order kept)."""
+        fields = {x: getattr(self, x)[mask] for x in LINE_COLUMNS}
+        return LineTable(self.formula, self.molecule_id, local_iso_id=self.local_iso_id[mask],
+                         isoid=self.isoid, mass=self.mass,
+                         tips_temperature=self.tips_temperature, tips_data=self.tips_data,
+                         **fields)
+
+
+class TotalPartitionFunction(object):
+    """TIPS table with the reference's interpolation (pyLBL/tips.py:26-39)."""
+    def __init__(self, molecule, temperature, data):
+        self.molecule = molecule
+        self.temperature = temperature
+        self.data = data
+
+    @property
+    def isotopologue(self):
+        return [x for x in range(self.data.shape[0])]
+
+    def total_partition_function(self, temperature, isotopologue):
+        i = isotopologue - 1
+        j = np.searchsorted(self.temperature, temperature, side="left") - 1
+        return self.data[i, j] + (self.data[i, j+1] - self.data[i, j]) * \
+            (temperature - self.temperature[j])/(self.temperature[j+1] - self.temperature[j])
+
+
+GasData = namedtuple("GasData", ["formula", "mass", "transitions", "partition_function"])
+
+
+class Database(object):
+    """Spectral line parameter database (read side).
+
+    Attributes:
+        path: String path to the SQLite file (what the reference's Gas stores,
+              pyLBL/c_lib/gas_optics.py:43).
+    """
+    def __init__(self, path):
+        self.path = str(path)
+
+    def _connect(self):
+        return sqlite3.connect(f"file:{self.path}?mode=ro", uri=True)
+
+    def _molecule_id(self, connection, name):
+        try:
+            row = connection.execute(
+                "select molecule from molecule_alias where alias == ?", (name,)).fetchone()
+        except sqlite3.OperationalError:
+            row = None
+        if row is None:
+            raise AliasNotFoundError(f"{name} not found in database.")
+        return int(row[0])
+
+    def molecules(self):
+        """Lists the chemical formulae of all molecules in the database."""
+        with self._connect() as connection:
+            rows = connection.execute("select ordinary_formula from molecule").fetchall()
+        return [x[0] for x in rows]
+
+    def tips(self, name):
+        """Returns (temperature[num_t], data[num_iso, num_t]) for a molecule alias."""
+        with self._connect() as connection:
+            return self._tips(connection, self._molecule_id(connection, name), name)
+
+    def _tips(self, connection, id, name):
+        rows = connection.execute(
+            "select isotopologue_id, temperature, data from tips where molecule_id == ?",
+            (id,)).fetchall()
+        if not rows:
+            raise TipsDataNotFoundError(f"no tips data for {name}.")
+        rows = np.asarray(rows, dtype=np.float64)
+        num_iso = 1 + int(np.count_nonzero(np.diff(rows[:, 0])))
+        if rows.shape[0] % num_iso:
+            raise ValueError("tips data is not rectangular.")  # spectral_database.c:85-90
+        num_t = rows.shape[0]//num_iso
+        temperature = rows[:num_t, 1].copy()
+        data = rows[:, 2].reshape(num_iso, num_t).copy()
+        return temperature, data
+
+    def line_table(self, name):
+        """Reads everything the lines engine needs for one molecule, as arrays."""
+        with self._connect() as connection:
+            id = self._molecule_id(connection, name)
+            temperature, data = self._tips(connection, id, name)
+            iso = connection.execute(
+                "select isoid, mass from isotopologue where molecule_id == ?", (id,)).fetchall()
+            if not iso:
+                raise IsotopologuesNotFoundError(
+                    f"isotopologues not found for molecule {id}.")
+            rows = connection.execute(
+                "select nu, sw, gamma_air, gamma_self, n_air, elower, delta_air, "
+                "local_iso_id from transition where molecule_id == ?", (id,)).fetchall()
+            if not rows:
+                raise TransitionsNotFoundError(f"transitions not found for molecule {id}.")
+            formula = connection.execute(
+                "select ordinary_formula from molecule where id == ?", (id,)).fetchone()
+        rows = np.asarray(rows, dtype=np.float64)
+        columns = {x: np.ascontiguousarray(rows[:, i]) for i, x in enumerate(LINE_COLUMNS)}
+        return LineTable(
+            formula=formula[0] if formula else name, molecule_id=id,
+            local_iso_id=np.ascontiguousarray(rows[:, 7]).astype(np.int32),
+            isoid=np.asarray([x[0] for x in iso], dtype=np.int64),
+            mass=np.asarray([x[1] for x in iso], dtype=np.float64),
+            tips_temperature=temperature, tips_data=data, **columns)
+
+    def gas(self, name):
+        """Same return shape as pyLBL/database.py:350-367: (formula, masses in
+        isotopologue-row order, transitions in row order, TotalPartitionFunction).
+        Transitions come back as a numpy record array: ``t[i].nu``, ``t.nu``."""
+        table = self.line_table(name)
+        transitions = np.rec.fromarrays(
+            [getattr(table, x) for x in LINE_COLUMNS] + [table.local_iso_id],
+            names=list(LINE_COLUMNS) + ["local_iso_id"])
+        tips = TotalPartitionFunction(name, table.tips_temperature, table.tips_data)
+        return GasData(table.formula, list(table.mass), transitions, tips)
+
+
+# Exact DDL of the reference's schema (pyLBL/database.py:418-486 as emitted by
+# SQLAlchemy's create_all); note the misspelt "molcule_id" column of artscrossfit.
+SCHEMA = """
+CREATE TABLE molecule (id INTEGER NOT NULL, stoichiometric_formula VARCHAR,
+    ordinary_formula VARCHAR, common_name VARCHAR, PRIMARY KEY (id));
+CREATE TABLE isotopologue (id INTEGER NOT NULL, molecule_id INTEGER, isoid INTEGER,
+    iso_name VARCHAR, abundance FLOAT, mass FLOAT, PRIMARY KEY (id),
+    FOREIGN KEY(molecule_id) REFERENCES molecule (id));
+CREATE TABLE molecule_alias (id INTEGER NOT NULL, alias VARCHAR, molecule INTEGER,
+    PRIMARY KEY (id), FOREIGN KEY(molecule) REFERENCES molecule (id));
+CREATE TABLE transition (id INTEGER NOT NULL, global_iso_id INTEGER, molecule_id INTEGER,
+    local_iso_id INTEGER, nu FLOAT, sw FLOAT, gamma_air FLOAT, gamma_self FLOAT,
+    n_air FLOAT, delta_air FLOAT, elower FLOAT, PRIMARY KEY (id),
+    FOREIGN KEY(molecule_id) REFERENCES molecule (id));
+CREATE TABLE tips (id INTEGER NOT NULL, molecule_id INTEGER, isotopologue_id INTEGER,
+    temperature FLOAT, data FLOAT, PRIMARY KEY (id),
+    FOREIGN KEY(molecule_id) REFERENCES molecule (id));
+CREATE TABLE artscrossfit (id INTEGER NOT NULL, molcule_id INTEGER, path VARCHAR,
+    PRIMARY KEY (id), FOREIGN KEY(molcule_id) REFERENCES molecule (id));
+CREATE TABLE metadata (id INTEGER NOT NULL, molecule_id INTEGER, database VARCHAR,
+    time VARCHAR, PRIMARY KEY (id), FOREIGN KEY(molecule_id) REFERENCES molecule (id));
+"""
+
+
+def write_database(path, tables, with_tips=None, aliases=None):
+    """Writes LineTables into a fresh SQLite file with the reference's schema.
+
+    Used for fixtures and benchmarks (no HITRAN data exists offline).  Row order of
+    every table is the array order, which is what the reference's readers rely on
+    (pyLBL/database.py:80-127).
+
+    Args:
+        path: Output file (overwritten).
+        tables: Iterable of LineTable.
+        with_tips: Optional set of formulae to write TIPS rows for (default: all).
+        aliases: Optional dict formula -> extra alias strings.
+    """
+    import os
+    if os.path.exists(path):
+        os.remove(path)
+    connection = sqlite3.connect(str(path))
+    connection.executescript(SCHEMA)
+    for table in tables:
+        id = int(table.molecule_id)
+        connection.execute("insert into molecule values (?, ?, ?, ?)",
+                           (id, table.formula, table.formula, table.formula))
+        names = [table.formula] + list((aliases or {}).get(table.formula, []))
+        connection.executemany("insert into molecule_alias (alias, molecule) values (?, ?)",
+                               [(x, id) for x in names])
+        connection.executemany(
+            "insert into isotopologue (molecule_id, isoid, iso_name, abundance, mass) "
+            "values (?, ?, ?, ?, ?)",
+            [(id, int(i), f"{table.formula}-{int(i)}", 1., float(m))
+             for i, m in zip(table.isoid, table.mass)])
+        connection.executemany(
+            "insert into transition (global_iso_id, molecule_id, local_iso_id, nu, sw, "
+            "gamma_air, gamma_self, n_air, delta_air, elower) values (?,?,?,?,?,?,?,?,?,?)",
+            zip([0]*table.num_lines, [id]*table.num_lines, table.local_iso_id.tolist(),
+                table.nu.tolist(), table.sw.tolist(), table.gamma_air.tolist(),
+                table.gamma_self.tolist(), table.n_air.tolist(), table.delta_air.tolist(),
+                table.elower.tolist()))
+        if with_tips is None or table.formula in with_tips:
+            num_iso, num_t = table.tips_data.shape
+            t = table.tips_temperature.tolist()
+            for iso in range(num_iso):
+                connection.executemany(
+                    "insert into tips (molecule_id, isotopologue_id, temperature, data) "
+                    "values (?, ?, ?, ?)",
+                    zip([id]*num_t, [iso]*num_t, t, table.tips_data[iso].tolist()))
+    connection.commit()
+    connection.close()
+    return str(path)
