@@ -1,0 +1,134 @@
+/*
+ * lbl_amd.h -- C ABI of the MI355X (gfx950) molecular-lines engine.
+ *
+ * This is the drop-in boundary for the lines backend of GRIPS-code/pyLBL: the one
+ * native entry point the reference binds over ctypes is
+ *
+ *     int absorption(double pressure, double temperature, double volume_mixing_ratio,
+ *                    int v0, int vn, int n_per_v, double *k, char *database,
+ *                    char *formula, int cut_off, int remove_pedestal);
+ *                                        (pyLBL/c_lib/absorption.c:19-30, bound at
+ *                                         pyLBL/c_lib/gas_optics.py:68-91)
+ *
+ * That call re-opens the SQLite file, re-reads every transition of the molecule and
+ * computes ONE (level, molecule) spectrum on one CPU thread.  The replacement splits it
+ * into (1) a one-time upload of a molecule's line table to HBM and (2) a batched compute
+ * call over many atmospheric levels, and keeps a same-signature compatibility entry.
+ *
+ * Conventions: plain C types only; every function returns LBL_OK (0) or a non-zero
+ * status and never throws; the message for the last failure on a handle is available
+ * from lbl_last_error(); a handle may be used from one thread at a time (distinct
+ * handles are independent).  All arrays are caller-owned; "host" pointers are ordinary
+ * process memory, "device" pointers are HIP device allocations on the engine's GPU.
+ */
+#ifndef LBL_AMD_H_
+#define LBL_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBL_OK              0
+#define LBL_ERROR           1   /* generic failure (message in lbl_last_error)            */
+#define LBL_BAD_ARGUMENT    2
+#define LBL_NO_DEVICE       3   /* no usable gfx950 device / HIP runtime failure           */
+#define LBL_OUT_OF_RANGE    4   /* temperature outside the TIPS table, iso id without data  */
+
+/* Which rows of the table take part (reference: pyLBL/c_lib/absorption.c:80-83). */
+#define LBL_RANGE_REFERENCE 0   /* stop at the first row outside [v0-(cut+1), vn+cut+1]    */
+#define LBL_RANGE_SKIP      1   /* ignore out-of-range rows, keep going                     */
+
+/* Where the per-line scalars (shifted centre, widths, strength) are evaluated. */
+#define LBL_PREP_DEVICE     0   /* HIP kernel (default)                                     */
+#define LBL_PREP_HOST       1   /* host libm, same operation order as spectra.c:17-45       */
+
+/* lbl_compute flags */
+#define LBL_OUT_DEVICE      1   /* k is a device pointer                                    */
+#define LBL_ASYNC           2   /* return after enqueueing; pair with lbl_synchronize       */
+#define LBL_SCALE_DENSITY   4   /* multiply by number density P x /(kb T): the lines slot of
+                                   Spectroscopy.compute_absorption (spectroscopy.py:181-191) */
+#define LBL_ACCUMULATE      8   /* add into k instead of overwriting it                     */
+
+typedef struct lbl_engine lbl_engine;
+
+/* Creates an engine bound to HIP device `device`.  Fails with LBL_NO_DEVICE when the HIP
+ * runtime reports no such GPU: there is no CPU fallback. */
+int lbl_engine_create(int device, lbl_engine **engine);
+int lbl_engine_destroy(lbl_engine *engine);
+
+/* Message of the last failure on this handle ("" if none); engine may be NULL to read the
+ * message of a failed lbl_engine_create on the calling thread. */
+const char *lbl_last_error(const lbl_engine *engine);
+
+/* Uploads one molecule: replaces the per-call SQLite row loop of absorption.c:44-86
+ * (tips_data, mass_data, line_parameters of spectral_database.c:49-180).
+ *   rows in reference row order; local_iso_id raw (0 means isotopologue 10);
+ *   mass[32] indexed isoid-1 (isoid 0 at slot 9);
+ *   tips_temperature[num_t]; tips_data[num_iso*num_t] isotopologue-major.
+ * On success *molecule receives a small non-negative handle. */
+int lbl_molecule_load(lbl_engine *engine, int64_t n_lines,
+                      const double *nu, const double *sw, const double *gamma_air,
+                      const double *gamma_self, const double *n_air, const double *elower,
+                      const double *delta_air, const int32_t *local_iso_id,
+                      const double *mass, int32_t num_iso, int32_t num_t,
+                      const double *tips_temperature, const double *tips_data,
+                      int32_t *molecule);
+int lbl_molecule_free(lbl_engine *engine, int32_t molecule);
+
+/* Absorption cross-section spectra [m2 molecule-1] of one molecule at n_levels levels:
+ * the batched form of absorption() (absorption.c:19-99).
+ *   k: n_levels rows of (vn-v0)*n_per_v doubles, row stride level_stride doubles
+ *      (0 means dense); host memory unless LBL_OUT_DEVICE.
+ *   evals (optional): sum over accepted lines and levels of last-first+1, the
+ *      reference's inner-loop iteration count (spectra.c:48-62), computed in closed form. */
+int lbl_compute(lbl_engine *engine, int32_t molecule, int32_t n_levels,
+                const double *temperature, const double *pressure, const double *vmr,
+                int32_t v0, int32_t vn, int32_t n_per_v, int32_t cut_off,
+                int32_t remove_pedestal, int32_t range_policy, int32_t flags,
+                double *k, int64_t level_stride, int64_t *evals);
+
+/* Waits for everything enqueued on the engine's stream. */
+int lbl_synchronize(lbl_engine *engine);
+
+/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic), "timing" (0/1: record
+ * HIP events around every kernel), "tile_order" (0 natural, 1 heaviest first). */
+int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
+
+/* With option timing=1: accumulated kernel milliseconds and launch counts since the last
+ * reset; index 0 line-scalar prep, 1 tile schedule, 2 Voigt accumulate, 3 pedestal.
+ * Synchronizes the stream. */
+int lbl_timing(lbl_engine *engine, double ms[4], int64_t launches[4], int32_t reset);
+
+/* The engine's HIP stream (a hipStream_t), for callers that time with their own events. */
+void *lbl_stream(lbl_engine *engine);
+
+/* Device memory helpers so that hosts without a HIP binding can keep spectra in HBM. */
+int lbl_device_alloc(lbl_engine *engine, int64_t bytes, void **pointer);
+int lbl_device_free(lbl_engine *engine, void *pointer);
+int lbl_copy_to_host(lbl_engine *engine, void *host, const void *device, int64_t bytes);
+
+/* Debug/inspection: per-line scalars for one level as the engine computed them, in
+ * reference row order: n_lines x 8 doubles {centre, doppler hwhm, lorentz hwhm, strength,
+ * first index, last index, status (1 evaluated, 0 skipped, -1 not accepted), pedestal}. */
+int lbl_line_scalars(lbl_engine *engine, int32_t molecule, double temperature,
+                     double pressure, double vmr, int32_t v0, int32_t vn, int32_t n_per_v,
+                     int32_t cut_off, int32_t remove_pedestal, int32_t range_policy,
+                     double *derived);
+
+/* Same signature and semantics as the reference's absorption() (absorption.c:19-30):
+ * opens the SQLite file, uploads the molecule (cached per path+formula for the life of the
+ * process), computes one level on device 0.  Returns 0 on success, 1 on error (message on
+ * stderr), 0 with zeros when the molecule has no TIPS rows (absorption.c:53-59). */
+int lbl_absorption(double pressure, double temperature, double volume_mixing_ratio,
+                   int v0, int vn, int n_per_v, double *k, char *database, char *formula,
+                   int cut_off, int remove_pedestal);
+
+/* Library version string. */
+const char *lbl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

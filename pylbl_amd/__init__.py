@@ -1,1 +1,19 @@
-"""MI355X-native line-by-line molecular-lines engine (drop-in for pyLBL's lines backend)."""
+"""MI355X-native molecular-lines engine: a drop-in for pyLBL's lines backend.
+
+Names mirror ``pyLBL/__init__.py:1-5`` for the lines path: ``Gas``, ``Database``,
+``molecular_lines``, ``Spectroscopy``.  Importing the package does not touch the GPU; the
+first ``Gas``/``Engine`` does, and fails loudly if the HIP library or the device is missing.
+"""
+from .database import Database, LineTable, TotalPartitionFunction, write_database
+from .errors import AliasNotFoundError, EngineError, IsotopologuesNotFoundError, \
+                    TipsDataNotFoundError, TransitionsNotFoundError
+from .engine import DeviceSpectra, Engine, default_engine
+from .gas_optics import Gas
+from .plugins import continua, cross_sections, models, molecular_lines, register
+from .spectroscopy import Atmosphere, Spectroscopy, number_density
+
+__all__ = ["Gas", "Database", "LineTable", "TotalPartitionFunction", "write_database",
+           "Engine", "DeviceSpectra", "default_engine", "Spectroscopy", "Atmosphere",
+           "number_density", "molecular_lines", "continua", "cross_sections", "models",
+           "register", "AliasNotFoundError", "EngineError", "IsotopologuesNotFoundError",
+           "TipsDataNotFoundError", "TransitionsNotFoundError"]

@@ -1,0 +1,889 @@
+// Host side of the engine and the C ABI declared in include/lbl_amd.h.
+//
+// Replaces the body of the reference's absorption() (pyLBL/c_lib/absorption.c:19-99):
+//   * the per-call SQLite read (absorption.c:44-73) becomes a one-time upload of a
+//     wavenumber-sorted struct-of-arrays line table (lbl_molecule_load);
+//   * the row loop calling spectra()/voigt() (absorption.c:76-86) becomes three kernel
+//     launches per batch of levels: prepare_kernel (per-line scalars), schedule_kernel
+//     (per-tile cut points) and accumulate_kernel (the Voigt sums), plus the pedestal
+//     kernels when remove_pedestal is set.
+// There is no CPU compute path in this file: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/lbl_amd.h"
+#include "accumulate.h"
+#include "line_prep.h"
+#include "pedestal.h"
+#include "tile_schedule.h"
+
+namespace {
+
+using namespace lbl;
+
+thread_local std::string g_create_error;
+
+struct HipFailure
+{
+    std::string message;
+};
+
+#define HIP_TRY(call)                                                                     \
+    do {                                                                                  \
+        hipError_t status_ = (call);                                                      \
+        if (status_ != hipSuccess)                                                        \
+        {                                                                                 \
+            throw HipFailure{std::string(#call) + ": " + hipGetErrorString(status_)};     \
+        }                                                                                 \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer
+{
+    T * data = nullptr;
+    size_t capacity = 0;   // elements
+
+    void reserve(size_t count)
+    {
+        if (count <= capacity) return;
+        release();
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&data), count*sizeof(T)));
+        capacity = count;
+    }
+    void release()
+    {
+        if (data != nullptr)
+        {
+            (void)hipFree(data);
+            data = nullptr;
+            capacity = 0;
+        }
+    }
+    void upload(const T * host, size_t count, hipStream_t stream)
+    {
+        reserve(count);
+        if (count > 0)
+        {
+            HIP_TRY(hipMemcpyAsync(data, host, count*sizeof(T), hipMemcpyHostToDevice, stream));
+        }
+    }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer & operator=(const DeviceBuffer &) = delete;
+};
+
+struct Molecule
+{
+    long long n_lines = 0;
+    // Host copies: row order (for the range rule) and sorted order (host prep, inspection).
+    std::vector<double> nu_row;
+    bool ascending = true;
+    std::vector<int> order;                 // sorted position -> row
+    std::vector<double> column[7];          // sorted: nu, sw, gamma_air, gamma_self, n_air, elower, delta_air
+    std::vector<int> iso_slot;              // sorted
+    double mass[kMassSlots];
+    unsigned used_slots = 0;                // bit per isotopologue slot that has lines
+    double max_abs_delta = 0.;
+    int num_iso = 0, num_t = 0;
+    std::vector<double> tips_t, tips_q;
+    // Device copies (sorted).
+    DeviceBuffer<double> d_column[7];
+    DeviceBuffer<int> d_iso_slot, d_row, d_sorted_of_row;
+
+    LineTableView view() const
+    {
+        LineTableView v;
+        v.nu = d_column[0].data; v.sw = d_column[1].data; v.gamma_air = d_column[2].data;
+        v.gamma_self = d_column[3].data; v.n_air = d_column[4].data;
+        v.elower = d_column[5].data; v.delta_air = d_column[6].data;
+        v.iso_slot = d_iso_slot.data; v.row = d_row.data;
+        v.sorted_of_row = d_sorted_of_row.data; v.n_lines = n_lines;
+        return v;
+    }
+};
+
+enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3 };
+
+}  // namespace
+
+struct lbl_engine
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::vector<std::unique_ptr<Molecule>> molecules;
+
+    // Options.
+    int prep = LBL_PREP_DEVICE;
+    int points_per_lane = 0;
+    int timing = 0;
+    long long workspace_bytes = 4ll << 30;
+
+    // Workspace (grown on demand, reused across calls).
+    DeviceBuffer<LineWing> wing;
+    DeviceBuffer<LineCore> core;
+    DeviceBuffer<TileSchedule> schedule;
+    DeviceBuffer<LevelScalars> levels;
+    DeviceBuffer<double> staging;
+    DeviceBuffer<double> derived;
+    DeviceBuffer<unsigned long long> evals;
+    PedestalWorkspace pedestal;
+    LevelScalars * pinned_levels = nullptr;
+    size_t pinned_capacity = 0;
+
+    // Timing.
+    struct Span { hipEvent_t begin, end; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double time_ms[4] = {0., 0., 0., 0.};
+    long long launches[4] = {0, 0, 0, 0};
+
+    hipEvent_t take_event()
+    {
+        if (!event_pool.empty())
+        {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        return e;
+    }
+
+    template <typename F>
+    void timed(int kind, F && launch)
+    {
+        if (!timing)
+        {
+            launch();
+            return;
+        }
+        Span s{take_event(), take_event(), kind};
+        HIP_TRY(hipEventRecord(s.begin, stream));
+        launch();
+        HIP_TRY(hipEventRecord(s.end, stream));
+        spans.push_back(s);
+        if (spans.size() >= 4096) drain_spans();
+    }
+
+    void drain_spans()
+    {
+        for (auto & s : spans)
+        {
+            HIP_TRY(hipEventSynchronize(s.end));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s.begin, s.end));
+            time_ms[s.kind] += ms;
+            launches[s.kind] += 1;
+            event_pool.push_back(s.begin);
+            event_pool.push_back(s.end);
+        }
+        spans.clear();
+    }
+
+    void reserve_pinned(size_t count)
+    {
+        if (count <= pinned_capacity) return;
+        if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
+        pinned_levels = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_levels),
+                              count*sizeof(LevelScalars), hipHostMallocDefault));
+        pinned_capacity = count;
+    }
+};
+
+namespace {
+
+int fail(lbl_engine * engine, int code, const std::string & message)
+{
+    if (engine != nullptr) engine->error = message; else g_create_error = message;
+    return code;
+}
+
+Molecule * find_molecule(lbl_engine * engine, int32_t handle)
+{
+    if (handle < 0 || (size_t)handle >= engine->molecules.size()) return nullptr;
+    return engine->molecules[handle].get();
+}
+
+// spectral_database.c:97-104 with bounds checks the reference lacks.
+bool tips_value(const Molecule & m, double temperature, int slot, double * value)
+{
+    const double * t = m.tips_t.data() + (size_t)slot*m.num_t;
+    const double * q = m.tips_q.data() + (size_t)slot*m.num_t;
+    const int i = (int)(floor(temperature)) - (int)(t[0]);
+    if (i < 0 || i + 1 >= m.num_t) return false;
+    *value = q[i] + (q[i+1] - q[i])*(temperature - t[i])/(t[i+1] - t[i]);
+    return true;
+}
+
+bool fill_level(const Molecule & m, double temperature, double pressure, double vmr,
+                LevelScalars & lv, std::string & why)
+{
+    const double pa_to_atm = 9.86923e-6;            // spectra.c:13
+    const double r2 = 2*log(2)*8314.472;            // spectra.c:14
+    const double kb = 1.38064852e-23;               // spectroscopy.py:15
+    const double vlight = 2.99792458e8;
+    const double sqrln2 = sqrt(log(2.));
+    if (!(temperature > 0.) || !std::isfinite(temperature) || !std::isfinite(pressure) ||
+        !std::isfinite(vmr))
+    {
+        why = "temperature, pressure and mixing ratio must be finite (temperature > 0).";
+        return false;
+    }
+    std::memset(&lv, 0, sizeof(lv));
+    lv.temperature = temperature;
+    lv.p_atm = pressure*pa_to_atm;
+    lv.p_partial = lv.p_atm*vmr;
+    lv.tfact = 296./temperature;
+    lv.t_minus_ref = temperature - 296.;
+    lv.t_times_ref = temperature*296.;
+    lv.density = pressure*vmr/(kb*temperature);
+    double widest = 0.;
+    for (int slot = 0; slot < kMassSlots; ++slot)
+    {
+        lv.doppler[slot] = 0.;
+        lv.q_ratio[slot] = 0.;
+        if (!(m.used_slots & (1u << slot))) continue;
+        lv.doppler[slot] = sqrt(r2*temperature/m.mass[slot]);
+        widest = std::max(widest, lv.doppler[slot]);
+        double q_ref, q_t;
+        if (!tips_value(m, 296., slot, &q_ref) || !tips_value(m, temperature, slot, &q_t))
+        {
+            why = "temperature " + std::to_string(temperature) +
+                  " K (or 296 K) lies outside the partition-function table.";
+            return false;
+        }
+        lv.q_ratio[slot] = q_ref/q_t;
+    }
+    lv.shift_max = fabs(lv.p_atm)*m.max_abs_delta*(1. + 1.e-12) + 1.e-12;
+    // voigt.c:34: xlim0 = sqrt(15100 + y(40 - 3.6y)) <= 123.34 for every y.
+    lv.core_reach = 123.4/sqrln2/vlight*widest*(1. + 1.e-9);
+    return true;
+}
+
+int first_row_out_of_range(const Molecule & m, double nu_min, double nu_max)
+{
+    const auto & nu = m.nu_row;
+    if (m.ascending)
+    {
+        if (nu.empty() || nu.front() < nu_min) return 0;
+        return (int)(std::upper_bound(nu.begin(), nu.end(), nu_max) - nu.begin());
+    }
+    for (size_t i = 0; i < nu.size(); ++i)
+    {
+        if (nu[i] > nu_max || nu[i] < nu_min) return (int)i;   // absorption.c:80-83
+    }
+    return (int)nu.size();
+}
+
+int pick_points_per_lane(const lbl_engine * engine, int n_per_v)
+{
+    const int p = engine->points_per_lane;
+    if (p == 1 || p == 2 || p == 4 || p == 8) return p;
+    if (n_per_v >= 400) return 8;
+    if (n_per_v >= 100) return 4;
+    if (n_per_v >= 20) return 2;
+    return 1;
+}
+
+void launch_accumulate(int points, dim3 grid, hipStream_t stream, const AccumulateArgs & args)
+{
+    switch (points)
+    {
+    case 1: hipLaunchKernelGGL(accumulate_kernel<1>, grid, dim3(256), 0, stream, args); break;
+    case 2: hipLaunchKernelGGL(accumulate_kernel<2>, grid, dim3(256), 0, stream, args); break;
+    case 4: hipLaunchKernelGGL(accumulate_kernel<4>, grid, dim3(256), 0, stream, args); break;
+    default: hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, stream, args); break;
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+struct ComputeRequest
+{
+    int32_t molecule, n_levels;
+    const double * temperature, * pressure, * vmr;
+    int32_t v0, vn, n_per_v, cut_off, remove_pedestal, range_policy, flags;
+    double * k;
+    int64_t level_stride;
+    int64_t * evals;
+    double * derived;      // host, n_lines x 8 in row order, single level only
+};
+
+int compute(lbl_engine * engine, const ComputeRequest & rq)
+{
+    Molecule * m = find_molecule(engine, rq.molecule);
+    if (m == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "unknown molecule handle.");
+    if (rq.n_levels < 1 || rq.temperature == nullptr || rq.pressure == nullptr ||
+        rq.vmr == nullptr)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "need at least one level with T, P and x.");
+    }
+    if (rq.n_per_v < 1 || rq.vn <= rq.v0 || rq.cut_off < 0)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT,
+                    "need vn > v0, n_per_v >= 1 and cut_off >= 0 (grid must start on an "
+                    "integer wavenumber with spacing 1/integer).");
+    }
+    const long long n_long = (long long)(rq.vn - rq.v0)*rq.n_per_v;
+    if (n_long > 0x3fffffff)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "grid has more than 2^30 points.");
+    }
+    if (rq.k == nullptr && rq.derived == nullptr)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "k is NULL.");
+    }
+    GridSpec g;
+    g.v0 = rq.v0; g.vn = rq.vn; g.n_per_v = rq.n_per_v; g.cut_off = rq.cut_off;
+    g.n = (int)n_long;
+    g.dv = 1./rq.n_per_v;
+    const long long stride = rq.level_stride > 0 ? rq.level_stride : n_long;
+    if (stride < n_long) return fail(engine, LBL_BAD_ARGUMENT, "level_stride < grid points.");
+
+    RangeRule rule;
+    rule.policy = rq.range_policy == LBL_RANGE_SKIP ? 1 : 0;
+    rule.nu_min = rq.v0 - (rq.cut_off + 1);
+    rule.nu_max = rq.vn + rq.cut_off + 1;
+    rule.row_limit = first_row_out_of_range(*m, rule.nu_min, rule.nu_max);
+
+    const int points = pick_points_per_lane(engine, rq.n_per_v);
+    const int tile_points = 64*points;
+    const int n_tiles = (int)((n_long + tile_points - 1)/tile_points);
+    const int n_cells = rq.vn - rq.v0;
+    const bool out_device = (rq.flags & LBL_OUT_DEVICE) != 0;
+    const bool want_k = rq.k != nullptr;
+    const long long n_lines = m->n_lines;
+
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        hipStream_t stream = engine->stream;
+
+        // Levels per pass, bounded by the workspace budget.
+        const long long per_level = n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
+                                    (long long)n_tiles*sizeof(TileSchedule) +
+                                    (out_device ? 0 : n_long*8) +
+                                    (rq.remove_pedestal ? pedestal_bytes_per_level(n_lines, n_cells, rq.cut_off) : 0);
+        long long chunk = std::max(1ll, engine->workspace_bytes/std::max(per_level, 1ll));
+        chunk = std::min<long long>(chunk, rq.n_levels);
+        if (chunk > 65535) chunk = 65535;
+
+        engine->reserve_pinned((size_t)chunk);
+        engine->levels.reserve((size_t)chunk);
+        engine->wing.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
+        engine->core.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
+        engine->schedule.reserve((size_t)(chunk*n_tiles));
+        if (want_k && !out_device) engine->staging.reserve((size_t)(chunk*n_long));
+        if (rq.evals != nullptr)
+        {
+            engine->evals.reserve(1);
+            HIP_TRY(hipMemsetAsync(engine->evals.data, 0, sizeof(unsigned long long), stream));
+        }
+        if (rq.derived != nullptr) engine->derived.reserve((size_t)(std::max(n_lines, 1ll)*8));
+
+        std::vector<LineWing> host_wing;
+        std::vector<LineCore> host_core;
+        std::vector<double> host_derived;
+
+        for (long long base = 0; base < rq.n_levels; base += chunk)
+        {
+            const int count = (int)std::min<long long>(chunk, rq.n_levels - base);
+            // The previous pass may still be reading the pinned block.
+            if (base > 0) HIP_TRY(hipStreamSynchronize(stream));
+            for (int l = 0; l < count; ++l)
+            {
+                std::string why;
+                if (!fill_level(*m, rq.temperature[base + l], rq.pressure[base + l],
+                                rq.vmr[base + l], engine->pinned_levels[l], why))
+                {
+                    return fail(engine, LBL_OUT_OF_RANGE,
+                                "level " + std::to_string(base + l) + ": " + why);
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(engine->levels.data, engine->pinned_levels,
+                                   count*sizeof(LevelScalars), hipMemcpyHostToDevice, stream));
+
+            // K1: per-line scalars.
+            if (n_lines > 0 && engine->prep == LBL_PREP_HOST)
+            {
+                host_wing.resize((size_t)(count*n_lines));
+                host_core.resize((size_t)(count*n_lines));
+                if (rq.derived != nullptr) host_derived.assign((size_t)(n_lines*8), 0.);
+                unsigned long long total = 0;
+                for (int l = 0; l < count; ++l)
+                {
+                    for (long long j = 0; j < n_lines; ++j)
+                    {
+                        const bool ok = line_accepted(rule, m->column[0][j], m->order[j]);
+                        double * d = (rq.derived != nullptr && l == 0)
+                                     ? host_derived.data() + j*8 : nullptr;
+                        LineWing & w = host_wing[(size_t)(l*n_lines + j)];
+                        const int status = prepare_line(
+                            engine->pinned_levels[l], g, m->column[0][j], m->column[1][j],
+                            m->column[2][j], m->column[3][j], m->column[4][j], m->column[5][j],
+                            m->column[6][j], m->iso_slot[j], ok, w,
+                            host_core[(size_t)(l*n_lines + j)], d);
+                        if (status == 1 && w.last >= w.first) total += w.last - w.first + 1;
+                    }
+                }
+                engine->timed(kTimePrepare, [&] {
+                    HIP_TRY(hipMemcpyAsync(engine->wing.data, host_wing.data(),
+                                           host_wing.size()*sizeof(LineWing),
+                                           hipMemcpyHostToDevice, stream));
+                    HIP_TRY(hipMemcpyAsync(engine->core.data, host_core.data(),
+                                           host_core.size()*sizeof(LineCore),
+                                           hipMemcpyHostToDevice, stream));
+                });
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (rq.evals != nullptr) *rq.evals += (int64_t)total;
+            }
+            else if (n_lines > 0)
+            {
+                engine->timed(kTimePrepare, [&] {
+                    dim3 grid((unsigned)((n_lines + 255)/256), (unsigned)count);
+                    hipLaunchKernelGGL(prepare_kernel, grid, dim3(256), 0, stream, m->view(),
+                                       engine->levels.data, g, rule, engine->wing.data,
+                                       engine->core.data,
+                                       rq.derived != nullptr ? engine->derived.data : nullptr,
+                                       rq.evals != nullptr ? engine->evals.data : nullptr);
+                    HIP_TRY(hipGetLastError());
+                });
+            }
+
+            if (!want_k) continue;
+
+            // Tile cut points.
+            engine->timed(kTimeSchedule, [&] {
+                dim3 grid((unsigned)((n_tiles + 255)/256), (unsigned)count);
+                hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, stream,
+                                   m->d_column[0].data, (int)n_lines, engine->levels.data, g,
+                                   tile_points, n_tiles, engine->schedule.data);
+                HIP_TRY(hipGetLastError());
+            });
+
+            AccumulateArgs args;
+            args.wing = engine->wing.data;
+            args.core = engine->core.data;
+            args.schedule = engine->schedule.data;
+            args.levels = engine->levels.data;
+            args.pedestal_cell = nullptr;
+            args.pedestal_point = nullptr;
+            args.n_cells = n_cells;
+            args.level_stride = out_device ? stride : n_long;
+            args.k = out_device ? rq.k + base*stride : engine->staging.data;
+            args.n_lines = n_lines;
+            args.n_tiles = n_tiles;
+            args.n = g.n;
+            args.v0 = g.v0;
+            args.n_per_v = g.n_per_v;
+            args.dv = g.dv;
+            args.scale_density = (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0;
+            args.accumulate = (out_device && (rq.flags & LBL_ACCUMULATE)) ? 1 : 0;
+
+            if (rq.remove_pedestal && n_lines > 0)
+            {
+                engine->timed(kTimePedestal, [&] {
+                    pedestal_pass(engine->pedestal, stream, m->view(), engine->wing.data,
+                                  engine->core.data, g, count, n_cells);
+                });
+                args.pedestal_cell = engine->pedestal.cell_sum.data;
+                args.pedestal_point = engine->pedestal.point_sum.data;
+            }
+
+            engine->timed(kTimeAccumulate, [&] {
+                dim3 grid((unsigned)((n_tiles + 3)/4), (unsigned)count);
+                launch_accumulate(points, grid, stream, args);
+            });
+
+            if (!out_device)
+            {
+                if (stride == n_long && !(rq.flags & LBL_ACCUMULATE))
+                {
+                    HIP_TRY(hipMemcpyAsync(rq.k + base*stride, engine->staging.data,
+                                           (size_t)count*n_long*8, hipMemcpyDeviceToHost,
+                                           stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                }
+                else
+                {
+                    std::vector<double> tmp((size_t)count*n_long);
+                    HIP_TRY(hipMemcpyAsync(tmp.data(), engine->staging.data, tmp.size()*8,
+                                           hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    for (int l = 0; l < count; ++l)
+                    {
+                        double * dst = rq.k + (base + l)*stride;
+                        const double * src = tmp.data() + (size_t)l*n_long;
+                        if (rq.flags & LBL_ACCUMULATE)
+                        {
+                            for (long long i = 0; i < n_long; ++i) dst[i] += src[i];
+                        }
+                        else
+                        {
+                            std::memcpy(dst, src, (size_t)n_long*8);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (rq.evals != nullptr && !(engine->prep == LBL_PREP_HOST))
+        {
+            unsigned long long total = 0;
+            HIP_TRY(hipMemcpyAsync(&total, engine->evals.data, sizeof(total),
+                                   hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            *rq.evals = (int64_t)total;
+        }
+        if (rq.derived != nullptr)
+        {
+            // Back to the reference's row order.
+            std::vector<double> sorted((size_t)(n_lines*8));
+            if (engine->prep == LBL_PREP_HOST)
+            {
+                sorted = host_derived;
+            }
+            else if (n_lines > 0)
+            {
+                HIP_TRY(hipMemcpyAsync(sorted.data(), engine->derived.data, sorted.size()*8,
+                                       hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            for (long long j = 0; j < n_lines; ++j)
+            {
+                std::memcpy(rq.derived + (size_t)m->order[j]*8, sorted.data() + (size_t)j*8, 64);
+            }
+        }
+        if (!(rq.flags & LBL_ASYNC))
+        {
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    catch (const std::bad_alloc &)
+    {
+        return fail(engine, LBL_ERROR, "host allocation failed.");
+    }
+    catch (const std::exception & e)
+    {
+        return fail(engine, LBL_ERROR, e.what());
+    }
+    return LBL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char * lbl_version(void)
+{
+    return "pylbl_amd 0.1 (gfx950)";
+}
+
+int lbl_engine_create(int device, lbl_engine ** engine)
+{
+    if (engine == nullptr) return fail(nullptr, LBL_BAD_ARGUMENT, "engine is NULL.");
+    *engine = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    {
+        return fail(nullptr, LBL_NO_DEVICE,
+                    "no HIP device visible: this engine has no CPU fallback.");
+    }
+    if (device < 0 || device >= count)
+    {
+        return fail(nullptr, LBL_NO_DEVICE, "device index out of range.");
+    }
+    try
+    {
+        HIP_TRY(hipSetDevice(device));
+        std::unique_ptr<lbl_engine> e(new lbl_engine());
+        e->device = device;
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        *engine = e.release();
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(nullptr, LBL_NO_DEVICE, f.message);
+    }
+    return LBL_OK;
+}
+
+int lbl_engine_destroy(lbl_engine * engine)
+{
+    if (engine == nullptr) return LBL_OK;
+    (void)hipSetDevice(engine->device);
+    if (engine->stream != nullptr) (void)hipStreamSynchronize(engine->stream);
+    for (auto & s : engine->spans)
+    {
+        (void)hipEventDestroy(s.begin);
+        (void)hipEventDestroy(s.end);
+    }
+    for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
+    if (engine->pinned_levels != nullptr) (void)hipHostFree(engine->pinned_levels);
+    engine->molecules.clear();
+    hipStream_t stream = engine->stream;
+    delete engine;
+    if (stream != nullptr) (void)hipStreamDestroy(stream);
+    return LBL_OK;
+}
+
+const char * lbl_last_error(const lbl_engine * engine)
+{
+    return engine != nullptr ? engine->error.c_str() : g_create_error.c_str();
+}
+
+int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
+                      const double * nu, const double * sw, const double * gamma_air,
+                      const double * gamma_self, const double * n_air, const double * elower,
+                      const double * delta_air, const int32_t * local_iso_id,
+                      const double * mass, int32_t num_iso, int32_t num_t,
+                      const double * tips_temperature, const double * tips_data,
+                      int32_t * molecule)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (molecule == nullptr || n_lines < 0 || n_lines > 0x7fffffff || mass == nullptr ||
+        tips_temperature == nullptr || tips_data == nullptr || num_iso < 1 || num_t < 2 ||
+        (n_lines > 0 && (nu == nullptr || sw == nullptr || gamma_air == nullptr ||
+                         gamma_self == nullptr || n_air == nullptr || elower == nullptr ||
+                         delta_air == nullptr || local_iso_id == nullptr)))
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "lbl_molecule_load: bad argument.");
+    }
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        std::unique_ptr<Molecule> m(new Molecule());
+        m->n_lines = n_lines;
+        m->num_iso = num_iso;
+        m->num_t = num_t;
+        std::memcpy(m->mass, mass, sizeof(m->mass));
+        m->tips_t.resize((size_t)num_iso*num_t);
+        for (int iso = 0; iso < num_iso; ++iso)
+        {
+            std::memcpy(m->tips_t.data() + (size_t)iso*num_t, tips_temperature, num_t*8);
+        }
+        m->tips_q.assign(tips_data, tips_data + (size_t)num_iso*num_t);
+        m->nu_row.assign(nu, nu + n_lines);
+        m->ascending = std::is_sorted(m->nu_row.begin(), m->nu_row.end());
+        m->order.resize((size_t)n_lines);
+        std::iota(m->order.begin(), m->order.end(), 0);
+        if (!m->ascending)
+        {
+            std::stable_sort(m->order.begin(), m->order.end(),
+                             [&](int a, int b) { return nu[a] < nu[b]; });
+        }
+        const double * source[7] = {nu, sw, gamma_air, gamma_self, n_air, elower, delta_air};
+        for (int c = 0; c < 7; ++c)
+        {
+            m->column[c].resize((size_t)n_lines);
+            for (long long j = 0; j < n_lines; ++j) m->column[c][j] = source[c][m->order[j]];
+        }
+        m->iso_slot.resize((size_t)n_lines);
+        for (long long j = 0; j < n_lines; ++j)
+        {
+            if (!std::isfinite(m->column[0][j]))
+            {
+                return fail(engine, LBL_BAD_ARGUMENT, "non-finite line position.");
+            }
+            int iso = local_iso_id[m->order[j]];
+            if (iso == 0) iso = 10;                         // spectral_database.c:173-177
+            const int slot = iso - 1;
+            if (slot < 0 || slot >= kMassSlots || slot >= num_iso || !(m->mass[slot] > 0.))
+            {
+                return fail(engine, LBL_OUT_OF_RANGE,
+                            "row " + std::to_string(m->order[j]) + ": local_iso_id " +
+                            std::to_string(local_iso_id[m->order[j]]) +
+                            " has no mass or no partition-function row.");
+            }
+            m->iso_slot[j] = slot;
+            m->used_slots |= 1u << slot;
+            m->max_abs_delta = std::max(m->max_abs_delta, fabs(m->column[6][j]));
+        }
+        hipStream_t stream = engine->stream;
+        for (int c = 0; c < 7; ++c) m->d_column[c].upload(m->column[c].data(), n_lines, stream);
+        m->d_iso_slot.upload(m->iso_slot.data(), n_lines, stream);
+        m->d_row.upload(m->order.data(), n_lines, stream);
+        std::vector<int> inverse((size_t)n_lines);
+        for (long long j = 0; j < n_lines; ++j) inverse[m->order[j]] = (int)j;
+        m->d_sorted_of_row.upload(inverse.data(), n_lines, stream);
+        HIP_TRY(hipStreamSynchronize(stream));
+        // Reuse a freed slot if there is one.
+        size_t slot = engine->molecules.size();
+        for (size_t i = 0; i < engine->molecules.size(); ++i)
+        {
+            if (!engine->molecules[i]) { slot = i; break; }
+        }
+        if (slot == engine->molecules.size()) engine->molecules.emplace_back();
+        engine->molecules[slot] = std::move(m);
+        *molecule = (int32_t)slot;
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    catch (const std::bad_alloc &)
+    {
+        return fail(engine, LBL_ERROR, "host allocation failed.");
+    }
+    return LBL_OK;
+}
+
+int lbl_molecule_free(lbl_engine * engine, int32_t molecule)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (find_molecule(engine, molecule) == nullptr)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "unknown molecule handle.");
+    }
+    (void)hipSetDevice(engine->device);
+    (void)hipStreamSynchronize(engine->stream);
+    engine->molecules[molecule].reset();
+    return LBL_OK;
+}
+
+int lbl_compute(lbl_engine * engine, int32_t molecule, int32_t n_levels,
+                const double * temperature, const double * pressure, const double * vmr,
+                int32_t v0, int32_t vn, int32_t n_per_v, int32_t cut_off,
+                int32_t remove_pedestal, int32_t range_policy, int32_t flags,
+                double * k, int64_t level_stride, int64_t * evals)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (k == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "k is NULL.");
+    if (evals != nullptr) *evals = 0;
+    ComputeRequest rq{molecule, n_levels, temperature, pressure, vmr, v0, vn, n_per_v, cut_off,
+                      remove_pedestal, range_policy, flags, k, level_stride, evals, nullptr};
+    return compute(engine, rq);
+}
+
+int lbl_line_scalars(lbl_engine * engine, int32_t molecule, double temperature,
+                     double pressure, double vmr, int32_t v0, int32_t vn, int32_t n_per_v,
+                     int32_t cut_off, int32_t remove_pedestal, int32_t range_policy,
+                     double * derived)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (derived == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "derived is NULL.");
+    (void)remove_pedestal;
+    ComputeRequest rq{molecule, 1, &temperature, &pressure, &vmr, v0, vn, n_per_v, cut_off,
+                      0, range_policy, 0, nullptr, 0, nullptr, derived};
+    return compute(engine, rq);
+}
+
+int lbl_synchronize(lbl_engine * engine)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    (void)hipSetDevice(engine->device);
+    hipError_t status = hipStreamSynchronize(engine->stream);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
+{
+    if (engine == nullptr || name == nullptr) return LBL_BAD_ARGUMENT;
+    const std::string key(name);
+    if (key == "prep" && (value == LBL_PREP_DEVICE || value == LBL_PREP_HOST))
+    {
+        engine->prep = (int)value;
+    }
+    else if (key == "points_per_lane" &&
+             (value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
+    {
+        engine->points_per_lane = (int)value;
+    }
+    else if (key == "timing" && (value == 0 || value == 1))
+    {
+        engine->timing = (int)value;
+    }
+    else if (key == "workspace_bytes" && value >= (1 << 20))
+    {
+        engine->workspace_bytes = value;
+    }
+    else
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "unknown option or value: " + key);
+    }
+    return LBL_OK;
+}
+
+int lbl_timing(lbl_engine * engine, double ms[4], int64_t launches[4], int32_t reset)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        HIP_TRY(hipStreamSynchronize(engine->stream));
+        engine->drain_spans();
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    for (int i = 0; i < 4; ++i)
+    {
+        if (ms != nullptr) ms[i] = engine->time_ms[i];
+        if (launches != nullptr) launches[i] = engine->launches[i];
+        if (reset)
+        {
+            engine->time_ms[i] = 0.;
+            engine->launches[i] = 0;
+        }
+    }
+    return LBL_OK;
+}
+
+void * lbl_stream(lbl_engine * engine)
+{
+    return engine != nullptr ? (void *)engine->stream : nullptr;
+}
+
+int lbl_device_alloc(lbl_engine * engine, int64_t bytes, void ** pointer)
+{
+    if (engine == nullptr || pointer == nullptr || bytes < 0) return LBL_BAD_ARGUMENT;
+    (void)hipSetDevice(engine->device);
+    hipError_t status = hipMalloc(pointer, (size_t)std::max<int64_t>(bytes, 8));
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_device_free(lbl_engine * engine, void * pointer)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    (void)hipSetDevice(engine->device);
+    (void)hipStreamSynchronize(engine->stream);
+    hipError_t status = hipFree(pointer);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int64_t bytes)
+{
+    if (engine == nullptr || host == nullptr || device == nullptr || bytes < 0)
+    {
+        return LBL_BAD_ARGUMENT;
+    }
+    (void)hipSetDevice(engine->device);
+    hipError_t status = hipMemcpyAsync(host, device, (size_t)bytes, hipMemcpyDeviceToHost,
+                                       engine->stream);
+    if (status == hipSuccess) status = hipStreamSynchronize(engine->stream);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+}  // extern "C"
+
+#include "sqlite_entry.inc"

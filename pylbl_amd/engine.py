@@ -1,0 +1,216 @@
+"""ctypes binding of the C ABI in include/lbl_amd.h (pylbl_amd/liblbl_amd.so).
+
+This is the only Python<->native boundary of the package, the counterpart of
+pyLBL/c_lib/gas_optics.py:11-26,68-91 in the reference.  There is no CPU fallback: if the
+library is missing or no MI355X is visible, creating an Engine raises.
+"""
+from ctypes import CDLL, POINTER, byref, c_char_p, c_double, c_int32, c_int64, c_void_p
+from pathlib import Path
+
+import numpy as np
+
+from .errors import EngineError
+
+LIBRARY_PATH = Path(__file__).resolve().parent / "liblbl_amd.so"
+
+# Mirrors of the #defines in include/lbl_amd.h.
+LBL_OK = 0
+RANGE_REFERENCE, RANGE_SKIP = 0, 1
+PREP_DEVICE, PREP_HOST = 0, 1
+OUT_DEVICE, ASYNC, SCALE_DENSITY, ACCUMULATE = 1, 2, 4, 8
+RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
+
+EXPORTED_SYMBOLS = (
+    "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
+    "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
+    "lbl_stream", "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
+    "lbl_line_scalars", "lbl_absorption", "lbl_version",
+)
+
+_library = None
+
+
+def library():
+    """Loads liblbl_amd.so (once) and declares the argument types of every entry point."""
+    global _library
+    if _library is not None:
+        return _library
+    if not LIBRARY_PATH.exists():
+        raise EngineError(
+            f"{LIBRARY_PATH} is missing: build it with `python -m pylbl_amd.build` "
+            "(there is no CPU fallback).")
+    lib = CDLL(str(LIBRARY_PATH))
+    f64p, i32p, i64p = POINTER(c_double), POINTER(c_int32), POINTER(c_int64)
+    lib.lbl_engine_create.argtypes = [c_int32, POINTER(c_void_p)]
+    lib.lbl_engine_destroy.argtypes = [c_void_p]
+    lib.lbl_last_error.argtypes = [c_void_p]
+    lib.lbl_last_error.restype = c_char_p
+    lib.lbl_molecule_load.argtypes = [c_void_p, c_int64] + [c_void_p]*7 + [c_void_p, c_void_p,
+                                     c_int32, c_int32, c_void_p, c_void_p, i32p]
+    lib.lbl_molecule_free.argtypes = [c_void_p, c_int32]
+    lib.lbl_compute.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p] + \
+                               [c_int32]*7 + [c_void_p, c_int64, i64p]
+    lib.lbl_synchronize.argtypes = [c_void_p]
+    lib.lbl_set_option.argtypes = [c_void_p, c_char_p, c_int64]
+    lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
+    lib.lbl_stream.argtypes = [c_void_p]
+    lib.lbl_stream.restype = c_void_p
+    lib.lbl_device_alloc.argtypes = [c_void_p, c_int64, POINTER(c_void_p)]
+    lib.lbl_device_free.argtypes = [c_void_p, c_void_p]
+    lib.lbl_copy_to_host.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
+    lib.lbl_line_scalars.argtypes = [c_void_p, c_int32] + [c_double]*3 + [c_int32]*6 + [c_void_p]
+    lib.lbl_absorption.argtypes = [c_double]*3 + [c_int32]*3 + [c_void_p, c_char_p, c_char_p,
+                                  c_int32, c_int32]
+    lib.lbl_version.restype = c_char_p
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("lbl_last_error", "lbl_stream", "lbl_version"):
+            getattr(lib, name).restype = c_int32
+    _library = lib
+    return lib
+
+
+def _f64(array):
+    return np.ascontiguousarray(array, dtype=np.float64)
+
+
+class DeviceSpectra(object):
+    """Spectra left in HBM: [levels, n] float64 on the engine's GPU."""
+    def __init__(self, engine, levels, n):
+        self.engine = engine
+        self.shape = (int(levels), int(n))
+        self.pointer = c_void_p()
+        engine._check(engine.lib.lbl_device_alloc(engine.handle, self.shape[0]*self.shape[1]*8,
+                                                  byref(self.pointer)))
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self.engine._check(self.engine.lib.lbl_copy_to_host(
+            self.engine.handle, out.ctypes.data, self.pointer, out.nbytes))
+        return out
+
+    def free(self):
+        if self.pointer:
+            self.engine.lib.lbl_device_free(self.engine.handle, self.pointer)
+            self.pointer = c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine(object):
+    """One GPU's engine: resident line tables plus the batched compute call."""
+    def __init__(self, device=0):
+        self.lib = library()
+        self.handle = c_void_p()
+        status = self.lib.lbl_engine_create(int(device), byref(self.handle))
+        if status != LBL_OK:
+            message = self.lib.lbl_last_error(None).decode()
+            self.handle = c_void_p()
+            raise EngineError(f"lbl_engine_create failed ({status}): {message}")
+        self.device = int(device)
+
+    def _check(self, status):
+        if status != LBL_OK:
+            raise EngineError(f"status {status}: {self.lib.lbl_last_error(self.handle).decode()}")
+
+    def close(self):
+        if self.handle:
+            self.lib.lbl_engine_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        self._check(self.lib.lbl_set_option(self.handle, name.encode(), int(value)))
+
+    def load(self, table):
+        """Uploads a pylbl_amd.database.LineTable; returns the molecule handle."""
+        columns = [_f64(getattr(table, x)) for x in
+                   ("nu", "sw", "gamma_air", "gamma_self", "n_air", "elower", "delta_air")]
+        iso = np.ascontiguousarray(table.local_iso_id, dtype=np.int32)
+        mass = _f64(table.mass_by_slot())
+        tips_t = _f64(table.tips_temperature)
+        tips_q = _f64(table.tips_data)
+        if tips_q.ndim != 2 or tips_q.shape[1] != tips_t.size:
+            raise ValueError("tips_data must be [num_iso, num_t] with num_t temperatures.")
+        handle = c_int32(-1)
+        self._check(self.lib.lbl_molecule_load(
+            self.handle, columns[0].size, *[x.ctypes.data for x in columns], iso.ctypes.data,
+            mass.ctypes.data, tips_q.shape[0], tips_q.shape[1], tips_t.ctypes.data,
+            tips_q.ctypes.data, byref(handle)))
+        return handle.value
+
+    def free(self, molecule):
+        self._check(self.lib.lbl_molecule_free(self.handle, int(molecule)))
+
+    def compute(self, molecule, temperature, pressure, vmr, v0, vn, n_per_v, cut_off=25,
+                remove_pedestal=False, range_policy="reference", out=None, scale_density=False,
+                accumulate=False, asynchronous=False, want_evals=False):
+        """Cross sections [m2] for every level: returns float64[levels, (vn-v0)*n_per_v]
+        (or fills `out`: a host array or a DeviceSpectra)."""
+        t, p, x = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure)), \
+            _f64(np.atleast_1d(vmr))
+        if not (t.shape == p.shape == x.shape and t.ndim == 1):
+            raise ValueError("temperature, pressure and vmr must be 1-d and equally long.")
+        n = (int(vn) - int(v0))*int(n_per_v)
+        flags = (SCALE_DENSITY if scale_density else 0) | (ACCUMULATE if accumulate else 0) | \
+                (ASYNC if asynchronous else 0)
+        if isinstance(out, DeviceSpectra):
+            if out.shape != (t.size, n):
+                raise ValueError(f"out has shape {out.shape}, need {(t.size, n)}.")
+            pointer, flags = out.pointer, flags | OUT_DEVICE
+        else:
+            if out is None:
+                out = np.zeros((t.size, max(n, 0)), dtype=np.float64)
+            if out.shape != (t.size, n) or out.dtype != np.float64 or \
+                    not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be C-contiguous float64[levels, n].")
+            pointer = c_void_p(out.ctypes.data)
+        evals = c_int64(0)
+        self._check(self.lib.lbl_compute(
+            self.handle, int(molecule), t.size, t.ctypes.data, p.ctypes.data, x.ctypes.data,
+            int(v0), int(vn), int(n_per_v), int(cut_off), 1 if remove_pedestal else 0,
+            RANGE_POLICIES[range_policy], flags, pointer, 0,
+            byref(evals) if want_evals else None))
+        return (out, evals.value) if want_evals else out
+
+    def line_scalars(self, molecule, num_lines, temperature, pressure, vmr, v0, vn, n_per_v,
+                     cut_off=25, range_policy="reference"):
+        """Per-line derived scalars in reference row order (see lbl_line_scalars)."""
+        derived = np.zeros((max(int(num_lines), 1), 8), dtype=np.float64)
+        self._check(self.lib.lbl_line_scalars(
+            self.handle, int(molecule), float(temperature), float(pressure), float(vmr),
+            int(v0), int(vn), int(n_per_v), int(cut_off), 0, RANGE_POLICIES[range_policy],
+            derived.ctypes.data))
+        return derived[:int(num_lines)]
+
+    def synchronize(self):
+        self._check(self.lib.lbl_synchronize(self.handle))
+
+    def timing(self, reset=False):
+        """(milliseconds[4], launches[4]) for prepare, schedule, accumulate, pedestal."""
+        ms = (c_double*4)()
+        launches = (c_int64*4)()
+        self._check(self.lib.lbl_timing(self.handle, ms, launches, 1 if reset else 0))
+        return list(ms), list(launches)
+
+    @property
+    def stream(self):
+        return self.lib.lbl_stream(self.handle)
+
+
+_default_engines = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine per device (what Gas objects share)."""
+    if device not in _default_engines:
+        _default_engines[device] = Engine(device)
+    return _default_engines[device]

@@ -1,0 +1,104 @@
+"""The lines backend class: same constructor and method as the reference's ``Gas``
+(pyLBL/c_lib/gas_optics.py:29-92), computing on an MI355X through pylbl_amd.engine.
+
+Differences that do not change results: the line table is read from the database once, in
+the constructor, and stays resident in HBM (the reference re-opens SQLite and re-reads every
+transition on every call, absorption.c:44-86); ``absorption_coefficients`` (plural) is the
+batched form over many levels that Spectroscopy uses.
+"""
+import numpy as np
+
+from .engine import DeviceSpectra, default_engine
+from .errors import AliasNotFoundError, IsotopologuesNotFoundError, TipsDataNotFoundError, \
+                    TransitionsNotFoundError
+from .synthetic import grid_arguments
+
+
+class Gas(object):
+    """API for gas optics calculation.
+
+    Attributes:
+        database: String path to the spectral sqlite3 database.
+        formula: String chemical formula.
+        engine: pylbl_amd.engine.Engine the line table lives on.
+        molecule: Engine handle of the resident line table (None: nothing to compute).
+    """
+    def __init__(self, lines_database, formula, device=0, engine=None):
+        """Initializes the object.
+
+        Args:
+            lines_database: Database object (``.path``, ``.line_table(formula)``), or a
+                            pylbl_amd.database.LineTable to upload directly.
+            formula: String chemical formula.
+            device: GPU index.
+            engine: Optional Engine to share (default: the process-wide one per device).
+        """
+        self.formula = formula
+        self.engine = engine if engine is not None else default_engine(device)
+        self.molecule = None
+        self._deferred_error = None
+        if hasattr(lines_database, "line_table"):
+            self.database = lines_database.path
+            try:
+                table = lines_database.line_table(formula)
+            except AliasNotFoundError:
+                # Reference: the constructor succeeds, the C call returns 1
+                # (spectral_database.c:152-156) -> ValueError at compute time.
+                self._deferred_error = ValueError("Error inside c functions.")
+                table = None
+            except (TipsDataNotFoundError, TransitionsNotFoundError):
+                table = None    # absorption.c:53-59: rc 0 and a zero spectrum
+            except IsotopologuesNotFoundError:
+                self._deferred_error = ValueError("Error inside c functions.")
+                table = None
+        else:
+            self.database = None
+            table = lines_database
+        self.num_lines = table.num_lines if table is not None else 0
+        if table is not None:
+            self.molecule = self.engine.load(table)
+
+    def absorption_coefficient(self, temperature, pressure, volume_mixing_ratio, grid,
+                               remove_pedestal=False, cut_off=25, range_policy="reference"):
+        """Calculates absorption coefficient.
+
+        Args:
+            temperature: Temperature [K].
+            pressure: Pressure [Pa].
+            volume_mixing_ratio: Volume mixing ratio [mol mol-1].
+            grid: Numpy array defining the spectral grid [cm-1].
+            remove_pedestal: Flag specifying if a pedestal should be subtracted.
+            cut_off: Wavenumber cut-off distance [cm-1] from line centers.
+            range_policy: "reference" stops at the first row outside the grid +- (cut_off+1)
+                          like absorption.c:80-83; "skip" ignores such rows.
+
+        Returns:
+            Numpy array of absorption coefficients [m2]; like the reference it holds
+            (vn - v0)*n_per_v >= grid.size points, callers slice [:grid.size].
+        """
+        return self.absorption_coefficients([temperature], [pressure], [volume_mixing_ratio],
+                                            grid, remove_pedestal, cut_off, range_policy)[0]
+
+    def absorption_coefficients(self, temperature, pressure, volume_mixing_ratio, grid,
+                                remove_pedestal=False, cut_off=25, range_policy="reference",
+                                out=None, scale_density=False, accumulate=False):
+        """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v]."""
+        if self._deferred_error is not None:
+            raise self._deferred_error
+        v0, vn, n_per_v = grid_arguments(grid)
+        levels = np.atleast_1d(np.asarray(temperature, dtype=np.float64)).size
+        if self.molecule is None:
+            if isinstance(out, DeviceSpectra) or out is not None:
+                return out
+            return np.zeros((levels, (vn - v0)*n_per_v))
+        return self.engine.compute(self.molecule, temperature, pressure, volume_mixing_ratio,
+                                   v0, vn, n_per_v, cut_off=cut_off,
+                                   remove_pedestal=remove_pedestal, range_policy=range_policy,
+                                   out=out, scale_density=scale_density, accumulate=accumulate)
+
+    def __del__(self):
+        try:
+            if self.molecule is not None and self.engine.handle:
+                self.engine.free(self.molecule)
+        except Exception:
+            pass

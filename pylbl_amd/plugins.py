@@ -1,0 +1,28 @@
+"""Back-end registry with the shape of the reference's (pyLBL/plugins.py:7-34):
+``molecular_lines[name] -> class``, looked up by Spectroscopy; an unknown name is a KeyError
+(pyLBL/spectroscopy.py:118).
+
+The reference fills its dictionaries from the entry points of the distribution named
+"pyLBL" only, so a third-party engine cannot register through entry points; it joins by
+inserting itself, which is what ``register`` does (also into pyLBL's own dictionary when
+that package is importable).
+"""
+from .gas_optics import Gas
+
+molecular_lines = {"mi355x": Gas}
+cross_sections = {}
+continua = {}
+models = molecular_lines.keys()
+
+
+def register(name="mi355x", into=None):
+    """Adds the MI355X Gas class to a ``molecular_lines``-shaped dictionary.
+
+    Args:
+        name: Backend name to register under.
+        into: Dictionary to insert into; default tries ``pyLBL.plugins.molecular_lines``.
+    """
+    if into is None:
+        from pyLBL.plugins import molecular_lines as into  # noqa: raises if pyLBL is absent
+    into[name] = Gas
+    return into

@@ -1,0 +1,196 @@
+"""Host orchestration of the lines slot: the counterpart of
+``Spectroscopy.compute_absorption`` (pyLBL/spectroscopy.py:144-206) restricted to mechanism
+slot 0 ("lines"); continua (slot 1) and cross-sections (slot 2) are outside this build's
+scope and stay zero.
+
+What is kept from the reference: constructor keywords and the KeyError for an unknown
+backend name (:88-118); molecule-outer / level-inner semantics with no state carried between
+units (:166-191); beta[level, 0, :] = n * k[:grid.size] with n = P x /(kb T) (:18-29,
+:181-191); ``remove_pedestal`` defaulting to ``continua_backend == "mt_ckd"`` (:163-164);
+the three output formats (:208-235).
+
+What is different: all levels of a molecule go to the GPU in one batched call and the
+number-density scaling happens in the kernel epilogue; xarray is optional (not installed in
+this image) -- without it the atmosphere is a plain (p, t, vmr) tuple and the result a dict
+of numpy arrays with the same variable names.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from .errors import AliasNotFoundError, IsotopologuesNotFoundError, TipsDataNotFoundError, \
+                    TransitionsNotFoundError
+from .plugins import continua, cross_sections, molecular_lines
+
+kb = 1.38064852e-23  # Boltzmann constant [J K-1] (pyLBL/spectroscopy.py:15).
+
+MECHANISMS = ["lines", "continuum", "cross_section"]
+
+
+def number_density(temperature, pressure, volume_mixing_ratio):
+    """Ideal-gas number density [m-3] (pyLBL/spectroscopy.py:18-29)."""
+    return pressure*volume_mixing_ratio/(kb*temperature)
+
+
+_STANDARD_NAME_PREFIX = "mole_fraction_of_"
+_FORMULAE = {"water_vapor": "H2O", "carbon_dioxide": "CO2", "ozone": "O3",
+             "nitrous_oxide": "N2O", "carbon_monoxide": "CO", "methane": "CH4",
+             "oxygen": "O2", "nitrogen": "N2"}
+
+
+class Atmosphere(object):
+    """Pressure, temperature and gas mole fractions as numpy arrays.
+
+    Accepts a (p, t, vmr) tuple/namedtuple or dict with those keys -- vmr maps a chemical
+    formula to an array shaped like t -- or, when xarray is installed, a Dataset read by CF
+    standard_name the way pyLBL/atmosphere.py:21-47 does.
+    """
+    def __init__(self, atmosphere, mapping=None):
+        if hasattr(atmosphere, "data_vars"):
+            self._from_dataset(atmosphere, mapping)
+            return
+        if isinstance(atmosphere, dict):
+            p, t, vmr = atmosphere["p"], atmosphere["t"], atmosphere["vmr"]
+        else:
+            p, t, vmr = atmosphere.p, atmosphere.t, atmosphere.vmr
+        self.pressure = np.asarray(p, dtype=np.float64)
+        self.temperature = np.asarray(t, dtype=np.float64)
+        self.gases = {k: np.asarray(v, dtype=np.float64) for k, v in vmr.items()}
+        for name, value in self.gases.items():
+            if value.shape != self.temperature.shape:
+                raise ValueError(f"mole fraction of {name} is not shaped like temperature.")
+        self.dims = [f"dim_{i}" for i in range(self.temperature.ndim)]
+
+    def _from_dataset(self, dataset, mapping):
+        def find(standard_name):
+            for name, var in dataset.data_vars.items():
+                if var.attrs.get("standard_name") == standard_name:
+                    return var
+            raise ValueError(f"standard name {standard_name} not found in dataset.")
+        if mapping is None:
+            pressure, temperature = find("air_pressure"), find("air_temperature")
+            gases = {}
+            for var in dataset.data_vars.values():
+                name = var.attrs.get("standard_name", "")
+                if name.startswith(_STANDARD_NAME_PREFIX) and name.endswith("_in_air"):
+                    key = name[len(_STANDARD_NAME_PREFIX):-len("_in_air")]
+                    gases[_FORMULAE.get(key, key)] = var
+        else:
+            pressure, temperature = dataset[mapping["play"]], dataset[mapping["tlay"]]
+            gases = {k: dataset[v] for k, v in mapping["mole_fraction"].items()}
+        self.pressure = np.asarray(pressure.data, dtype=np.float64)
+        self.temperature = np.asarray(temperature.data, dtype=np.float64)
+        self.gases = {k: np.asarray(v.data, dtype=np.float64) for k, v in gases.items()}
+        self.dims = list(temperature.dims)
+
+
+class MoleculeCache(object):
+    """Caches the per-molecule backend object (pyLBL/spectroscopy.py:32-69); building it
+    uploads the molecule's line table to HBM once."""
+    def __init__(self, name, lines_database, lines_engine, device):
+        try:
+            self.gas = lines_engine(lines_database, name, device=device)
+        except (AliasNotFoundError, IsotopologuesNotFoundError,
+                TipsDataNotFoundError, TransitionsNotFoundError):
+            self.gas = None
+
+
+class Spectroscopy(object):
+    """Line-by-line gas optics (lines mechanism) on an MI355X.
+
+    Attributes mirror pyLBL/spectroscopy.py:72-86.
+    """
+    def __init__(self, atmosphere, grid, database, mapping=None, lines_backend="mi355x",
+                 continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0):
+        self.atmosphere = Atmosphere(atmosphere, mapping=mapping)
+        self.grid = np.asarray(grid, dtype=np.float64)
+        self.lines_database = database
+        self.lines_backend = lines_backend
+        self.lines_engine = molecular_lines[lines_backend]      # KeyError if unknown
+        self.continua_backend = continua_backend
+        self.continua_engine = continua.get(continua_backend)   # not built: slot 1 stays 0
+        self.cross_sections_backend = cross_sections_backend
+        self.cross_sections_engine = cross_sections.get(cross_sections_backend)
+        self.cache = {}
+        self.device = device
+        Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
+        dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
+        dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
+        self.output = Output(dims=dims, dim_sizes=dim_sizes, mechanisms=MECHANISMS,
+                             units={"units": "m-1"})
+
+    def list_molecules(self):
+        return self.lines_database.molecules()
+
+    def compute_absorption(self, output_format="all", remove_pedestal=None,
+                           range_policy="reference"):
+        """Computes the lines absorption coefficient [m-1] on the grid for every level and
+        gas of the atmosphere.
+
+        Args:
+            output_format: "all" (per gas, per mechanism), "gas" (per gas, mechanisms summed)
+                           or anything else for the total over gases (spectroscopy.py:208-235).
+            remove_pedestal: Subtract the MT-CKD "pedestal" (default: True when the continuum
+                             backend is "mt_ckd", as spectroscopy.py:163-164).
+
+        Returns:
+            xarray Dataset when xarray is installed, else a dict of numpy arrays with the
+            same variable names ("wavenumber", "mechanism", "<formula>_absorption" /
+            "absorption").
+        """
+        temperature = self.atmosphere.temperature.ravel()
+        pressure = self.atmosphere.pressure.ravel()
+        shape = self.atmosphere.temperature.shape
+        if remove_pedestal is None:
+            remove_pedestal = self.continua_backend == "mt_ckd"
+        beta = {}
+        for name, mole_fraction in self.atmosphere.gases.items():
+            varname = "{}_absorption".format(name)
+            lines = np.zeros((temperature.size, self.grid.size))
+            data = self.cache.get(name)
+            if data is None:
+                data = MoleculeCache(name, self.lines_database, self.lines_engine, self.device)
+                self.cache[name] = data
+            if data.gas is not None:
+                # One batched call for all levels; n*k is applied in the kernel epilogue.
+                k = data.gas.absorption_coefficients(
+                    temperature, pressure, mole_fraction.ravel(), self.grid,
+                    remove_pedestal=remove_pedestal, range_policy=range_policy,
+                    scale_density=True)
+                lines = k[:, :self.grid.size]
+            if output_format == "all":
+                values = np.zeros([temperature.size, len(MECHANISMS), self.grid.size])
+                values[:, 0, :] = lines
+                beta[varname] = values.reshape(self.output.dim_sizes)
+            else:
+                beta[varname] = np.ascontiguousarray(lines).reshape(
+                    list(shape) + [self.grid.size])
+        return self._create_output_dataset(beta, output_format)
+
+    def _create_output_dataset(self, absorption, output_format):
+        dims = list(self.output.dims)
+        if output_format == "all":
+            variables = dict(absorption)
+            extra = {"mechanism": np.asarray(self.output.mechanisms)}
+        elif output_format == "gas":
+            dims.pop(-2)
+            variables = dict(absorption)
+            extra = {}
+        else:
+            dims.pop(-2)
+            variables = {"absorption": sum(absorption.values())} if absorption else {}
+            extra = {}
+        try:
+            from xarray import DataArray, Dataset
+        except ImportError:
+            out = {"wavenumber": self.grid}
+            out.update(extra)
+            out.update(variables)
+            return out
+        data_vars = {"wavenumber": DataArray(self.grid, dims=("wavenumber",),
+                                             attrs={"units": "cm-1"})}
+        for key, value in extra.items():
+            data_vars[key] = DataArray(value, dims=("mechanism",))
+        for key, value in variables.items():
+            data_vars[key] = DataArray(value, dims=dims, attrs=self.output.units)
+        return Dataset(data_vars=data_vars)

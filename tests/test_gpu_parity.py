@@ -1,0 +1,158 @@
+"""Parity of the HIP engine against the golden vectors (reference's own compiled C) and
+against the CPU oracle on seeded inputs.  Everything here calls through the C ABI."""
+import numpy as np
+import pytest
+
+from tests import golden_io
+
+pytestmark = pytest.mark.gpu
+
+REL = 1.e-6   # BASELINE.json north_star: <= 1e-6 relative in fp64
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pylbl_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def assert_spectrum(k, k_ref, case, label):
+    assert k.shape == k_ref.shape
+    if case.remove_pedestal:
+        tol = golden_io.pedestal_tolerance(k_ref, case.n_per_v, case.cut_off, REL)
+        tol += 1e-300
+        worst = np.max(np.abs(k - k_ref)/tol)
+        assert worst <= 1., f"{label}: {worst:.3g} x the pedestal tolerance"
+    else:
+        nz = k_ref != 0
+        assert np.array_equal(k[~nz], k_ref[~nz]), f"{label}: nonzero where reference is zero"
+        if nz.any():
+            worst = np.max(np.abs(k[nz] - k_ref[nz])/np.abs(k_ref[nz]))
+            assert worst <= REL, f"{label}: max rel err {worst:.3g}"
+
+
+@pytest.mark.parametrize("prep", ["device", "host"])
+@pytest.mark.parametrize("group", golden_io.ABSORPTION_GROUPS)
+def test_golden_absorption(engine, group, prep):
+    engine.set_option("prep", 1 if prep == "host" else 0)
+    table, cases = golden_io.load_group(group)
+    molecule = engine.load(table)
+    try:
+        for case in cases:
+            k = engine.compute(molecule, case.temperature, case.pressure, case.vmr, case.v0,
+                               case.vn, case.n_per_v, cut_off=case.cut_off,
+                               remove_pedestal=case.remove_pedestal)[0]
+            assert_spectrum(k, case.k, case, f"{group}[{case.index}] prep={prep}")
+    finally:
+        engine.free(molecule)
+        engine.set_option("prep", 0)
+
+
+@pytest.mark.parametrize("points", [1, 2, 4, 8])
+def test_golden_every_tile_size(engine, points):
+    """Every template instance of the accumulate kernel on the densest fixtures."""
+    engine.set_option("points_per_lane", points)
+    try:
+        for group in ("co2_band", "h2o_nir", "clipping"):
+            table, cases = golden_io.load_group(group)
+            molecule = engine.load(table)
+            for case in cases:
+                k = engine.compute(molecule, case.temperature, case.pressure, case.vmr,
+                                   case.v0, case.vn, case.n_per_v, cut_off=case.cut_off,
+                                   remove_pedestal=case.remove_pedestal)[0]
+                assert_spectrum(k, case.k, case, f"{group}[{case.index}] P={points}")
+            engine.free(molecule)
+    finally:
+        engine.set_option("points_per_lane", 0)
+
+
+def test_batched_levels_equal_single_calls(engine):
+    table, cases = golden_io.load_group("co2_band")
+    cases = [c for c in cases if not c.remove_pedestal]
+    molecule = engine.load(table)
+    c0 = cases[0]
+    k = engine.compute(molecule, [c.temperature for c in cases], [c.pressure for c in cases],
+                       [c.vmr for c in cases], c0.v0, c0.vn, c0.n_per_v)
+    for i, case in enumerate(cases):
+        assert_spectrum(k[i], case.k, case, f"batched level {i}")
+    engine.free(molecule)
+
+
+def test_line_scalars_match_oracle(engine, oracle):
+    """Per-line derived scalars (spectra.c:17-62) from the device and the host prep."""
+    table, cases = golden_io.load_group("co2_band")
+    case = cases[3]
+    _, extras = oracle.absorption_port(table, case.temperature, case.pressure, case.vmr,
+                                       case.v0, case.vn, case.n_per_v, want_derived=True)
+    ref = extras["derived"]
+    molecule = engine.load(table)
+    for prep in (0, 1):
+        engine.set_option("prep", prep)
+        got = engine.line_scalars(molecule, table.num_lines, case.temperature, case.pressure,
+                                  case.vmr, case.v0, case.vn, case.n_per_v)
+        assert np.array_equal(got[:, 4:7], ref[:, 4:7])          # window and status: exact
+        np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=1e-13 if prep == 0 else 0.)
+    engine.set_option("prep", 0)
+    engine.free(molecule)
+
+
+def test_eval_count_matches_oracle(engine, oracle):
+    table, cases = golden_io.load_group("h2o_nir")
+    case = cases[0]
+    _, extras = oracle.absorption_port(table, case.temperature, case.pressure, case.vmr,
+                                       case.v0, case.vn, case.n_per_v)
+    molecule = engine.load(table)
+    _, evals = engine.compute(molecule, case.temperature, case.pressure, case.vmr, case.v0,
+                              case.vn, case.n_per_v, want_evals=True)
+    assert evals == extras["evals"]
+    engine.free(molecule)
+
+
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+def test_seeded_against_oracle_fine_grid(engine, oracle, remove_pedestal):
+    """A 0.001 cm-1 grid (the benchmark resolution) at sizes the oracle finishes in seconds,
+    all four fixture levels: exercises full-cover fast loops, core rows and clipping."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("CO2", 600., 668., num_lines=3000, seed=21)
+    atmos = synthetic.fixture_atmosphere()
+    v0, vn, npv = 600, 640, 1000
+    molecule = engine.load(table)
+    k = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
+                       remove_pedestal=remove_pedestal)
+    case = golden_io.Case("seeded", 0, 0, 0, 0, v0, vn, npv, 25, remove_pedestal, None, 0)
+    for i in range(atmos.t.size):
+        k_ref, _ = oracle.absorption_port(table, atmos.t[i], atmos.p[i], atmos.vmr["CO2"][i],
+                                          v0, vn, npv, remove_pedestal=remove_pedestal)
+        assert_spectrum(k[i], k_ref, case, f"seeded level {i}")
+    engine.free(molecule)
+
+
+def test_unsorted_rows_and_skip_policy(engine, oracle):
+    """Row order differs from wavenumber order; the reference rule stops at the first
+    out-of-range row, the skip rule does not."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("H2O", 1., 90., num_lines=200, seed=33,
+                                 tips_range=(150, 400))
+    rng = np.random.default_rng(5)
+    table = table.subset(rng.permutation(table.num_lines))
+    molecule = engine.load(table)
+    for ped in (False, True):
+        k = engine.compute(molecule, 288.99, 98388., 6.6e-3, 1, 61, 20, remove_pedestal=ped)[0]
+        k_ref, _ = oracle.absorption_port(table, 288.99, 98388., 6.6e-3, 1, 61, 20,
+                                          remove_pedestal=ped)
+        case = golden_io.Case("unsorted", 0, 0, 0, 0, 1, 61, 20, 25, ped, None, 0)
+        assert_spectrum(k, k_ref, case, f"unsorted ped={ped}")
+    # Grid 30..50: most rows lie outside [4, 76]; the reference rule keeps only the rows
+    # before the first such row, "skip" keeps every in-range row.
+    k_ref, _ = oracle.absorption_port(table, 288.99, 98388., 6.6e-3, 30, 50, 20)
+    k = engine.compute(molecule, 288.99, 98388., 6.6e-3, 30, 50, 20)[0]
+    case = golden_io.Case("unsorted", 1, 0, 0, 0, 30, 50, 20, 25, False, None, 0)
+    assert_spectrum(k, k_ref, case, "reference range rule")
+    inside = table.subset((table.nu >= 4.) & (table.nu <= 76.))
+    k_skip_ref, _ = oracle.absorption_port(inside, 288.99, 98388., 6.6e-3, 30, 50, 20)
+    k_skip = engine.compute(molecule, 288.99, 98388., 6.6e-3, 30, 50, 20,
+                            range_policy="skip")[0]
+    assert_spectrum(k_skip, k_skip_ref, case, "skip range rule")
+    engine.free(molecule)
