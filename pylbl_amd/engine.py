@@ -162,8 +162,9 @@ class Engine(object):
         n = (int(vn) - int(v0))*int(n_per_v)
         flags = (SCALE_DENSITY if scale_density else 0) | (ACCUMULATE if accumulate else 0) | \
                 (ASYNC if asynchronous else 0)
-        if isinstance(out, DeviceSpectra):
-            if out.shape != (t.size, n):
+        if hasattr(out, "pointer"):
+            # Device memory: a DeviceSpectra or anything exposing .pointer and .shape.
+            if tuple(out.shape) != (t.size, n):
                 raise ValueError(f"out has shape {out.shape}, need {(t.size, n)}.")
             pointer, flags = out.pointer, flags | OUT_DEVICE
         else:

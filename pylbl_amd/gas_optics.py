@@ -8,7 +8,7 @@ batched form over many levels that Spectroscopy uses.
 """
 import numpy as np
 
-from .engine import DeviceSpectra, default_engine
+from .engine import default_engine
 from .errors import AliasNotFoundError, IsotopologuesNotFoundError, TipsDataNotFoundError, \
                     TransitionsNotFoundError
 from .synthetic import grid_arguments
@@ -88,7 +88,7 @@ class Gas(object):
         v0, vn, n_per_v = grid_arguments(grid)
         levels = np.atleast_1d(np.asarray(temperature, dtype=np.float64)).size
         if self.molecule is None:
-            if isinstance(out, DeviceSpectra) or out is not None:
+            if out is not None:
                 return out
             return np.zeros((levels, (vn - v0)*n_per_v))
         return self.engine.compute(self.molecule, temperature, pressure, volume_mixing_ratio,
