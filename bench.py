@@ -56,6 +56,9 @@ def parse():
                         help="multiplies the HITRAN-like line counts")
     parser.add_argument("--points-per-lane", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--ablate", type=int, default=0,
+                        help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
+                             "(results are wrong; the line is marked invalid)")
     parser.add_argument("--cpu-sample-cm", type=float, default=600.,
                         help="width [cm-1] of the grid sample the CPU baseline is timed on")
     return parser.parse_args()
@@ -165,6 +168,8 @@ def main():
     engine = Engine(local_rank)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
+    if args.ablate:
+        engine.set_option("ablate", args.ablate)
     handles = [engine.load(t) for t in tables]
 
     # Spectra stay in HBM: [molecule, level, n] per rank (torch only owns the memory).
@@ -268,6 +273,8 @@ def main():
                 "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
                 "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
         }
+        if args.ablate:
+            line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, n_per_v,
                                                 args.cpu_sample_cm, args.pedestal)

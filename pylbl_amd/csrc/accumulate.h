@@ -52,84 +52,162 @@ struct AccumulateArgs
     double dv;
     int scale_density;
     int accumulate;
+    int ablate;                     // diagnostics only: 1 skips the general ranges, 2 the fast ranges
 };
 
+// Far-wing loop over two index ranges [a0,a1) and [b0,b1) whose lines all cover the whole
+// tile with the tile in their Lorentz wing.  Four lines share one reciprocal (lorentz_four);
+// only whole groups of four are taken here, the caller sends the 0-3 left-over lines of each
+// range down the general path.  The records arrive by scalar loads whose latency is covered
+// by the other resident wavefronts of the SIMD.
 template <int P>
-__device__ __forceinline__ void fast_range(const LineWing * __restrict__ wing, int j0, int j1,
-                                           const double (&v)[P], double (&acc)[P])
+__device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
+                                            int a0, int a1, int b0, int b1,
+                                            const double (&v)[P], double (&acc)[P])
 {
-    int j = j0;
-    for (; j + 4 <= j1; j += 4)
+    const int qa = (a1 - a0) >> 2;
+    const int quads = qa + ((b1 - b0) >> 2);
+    for (int q = 0; q < quads; ++q)
     {
+        const int j = q < qa ? a0 + 4*q : b0 + 4*(q - qa);
         const LineWing l1 = wing[j], l2 = wing[j + 1], l3 = wing[j + 2], l4 = wing[j + 3];
 #pragma unroll
         for (int p = 0; p < P; ++p)
         {
-            acc[p] += lorentz_four(v[p], l1.centre, l1.g2, l1.bl, l2.centre, l2.g2, l2.bl,
-                                   l3.centre, l3.g2, l3.bl, l4.centre, l4.g2, l4.bl);
+            acc[p] = lorentz_four(v[p], l1.centre, l1.g2, l1.bl, l2.centre, l2.g2, l2.bl,
+                                  l3.centre, l3.g2, l3.bl, l4.centre, l4.g2, l4.bl, acc[p]);
         }
     }
-    for (; j < j1; ++j)
+}
+
+// One line that may clip the tile or have its core in it, row by row (64 points each).
+// Per row the decisions are wave-uniform: skip (outside the window), Lorentz (whole row in
+// the far wing), or core.  In a core row every lane applies the reference's chain on
+// xi = (v-nu')*repwid (voigt.c:76-84): region 0 and w4 region 1 (voigt.c:95-96) are
+// evaluated inline; only lanes closer to the centre than xlim1 call wells_profile().
+template <int P>
+__device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
+                                             int i0, int i1, int lane,
+                                             const double (&v)[P], double (&acc)[P])
+{
+    if (l.last < i0 || l.first > i1)
     {
-        const LineWing l = wing[j];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-        {
-            acc[p] += lorentz_one(v[p], l.centre, l.g2, l.bl);
-        }
+        return;     // also skips empty windows
     }
+    const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
+    const double yq = c.y*c.y;
+    const double a0 = yq + 0.5;                      // voigt.c:91-93
+    const double d0 = a0*a0;
+    const double d2 = yq + yq - 1.;
+    const double r1_scale = c.amp*rsqrpi*c.y;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+    {
+        const int r0 = i0 + p*64;
+        const int r1 = r0 + 63;
+        if (l.last < r0 || l.first > r1)
+        {
+            continue;
+        }
+        const int i = r0 + lane;
+        const bool inside = (i >= l.first) && (i <= l.last);
+        const double d = v[p] - l.centre;
+        // voigt.c:82 / :24 in wavenumber units.
+        double value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+        if (!(c.core_last < r0 || c.core_first > r1))
+        {
+            const double xi = d*c.repwid;               // voigt.c:76
+            const double abx = fabs(xi);
+            const double xq = abx*abx;
+            if (abx < c.xlim0)
+            {
+                if (abx >= c.xlim1)
+                {
+                    // voigt.c:95-96: buf = rsqrpi/(d0 + xq(d2 + xq)) * y * (a0 + xq)
+                    value = r1_scale*(a0 + xq)*rcp_newton(d0 + xq*(d2 + xq));
+                }
+                else
+                {
+                    value = c.amp*wells_profile(xi, c.y);
+                }
+            }
+        }
+        acc[p] += inside ? value : 0.;
+    }
+}
+
+// Up to five index ranges of lines in general position, walked as one list; records are
+// fetched two lines at a time so that the scalar-load latency is paid once per pair.
+struct GeneralList
+{
+    int begin[5];
+    int count[5];
+};
+
+__device__ __forceinline__ int general_index(const GeneralList & g, int k)
+{
+    if (k < g.count[0]) return g.begin[0] + k;
+    k -= g.count[0];
+    if (k < g.count[1]) return g.begin[1] + k;
+    k -= g.count[1];
+    if (k < g.count[2]) return g.begin[2] + k;
+    k -= g.count[2];
+    if (k < g.count[3]) return g.begin[3] + k;
+    k -= g.count[3];
+    return g.begin[4] + k;
 }
 
 template <int P>
-__device__ __forceinline__ void general_range(const LineWing * __restrict__ wing,
-                                              const LineCore * __restrict__ core,
-                                              int j0, int j1, int i0, int i1, int lane,
-                                              const double (&v)[P], double (&acc)[P])
+__device__ __forceinline__ void general_ranges(const LineWing * __restrict__ wing,
+                                               const LineCore * __restrict__ core,
+                                               const GeneralList & g, int i0, int i1, int lane,
+                                               const double (&v)[P], double (&acc)[P])
 {
-    for (int j = j0; j < j1; ++j)
+    const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
+    int k = 0;
+    for (; k + 2 <= total; k += 2)
     {
-        const LineWing l = wing[j];
-        if (l.last < i0 || l.first > i1)
-        {
-            continue;   // also skips empty windows (first > last)
-        }
-        const LineCore c = core[j];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-        {
-            const int r0 = i0 + p*64;
-            const int r1 = r0 + 63;
-            if (l.last < r0 || l.first > r1)
-            {
-                continue;
-            }
-            const int i = r0 + lane;
-            const bool inside = (i >= l.first) && (i <= l.last);
-            const double d = v[p] - l.centre;
-            double value;
-            if (c.core_last < r0 || c.core_first > r1)
-            {
-                // Whole row beyond xlim0 (or a y >= 70.55 line): voigt.c:82 / :24.
-                value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-            }
-            else
-            {
-                // voigt.c:76,188 with the reference's region chain.
-                const double xi = d*c.repwid;
-                value = c.amp*wells_profile(xi, c.y);
-            }
-            acc[p] += inside ? value : 0.;
-        }
+        const int ja = general_index(g, k), jb = general_index(g, k + 1);
+        const LineWing la = wing[ja], lb = wing[jb];
+        const LineCore ca = core[ja], cb = core[jb];
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
+        general_line<P>(lb, cb, i0, i1, lane, v, acc);
+    }
+    if (k < total)
+    {
+        const int ja = general_index(g, k);
+        const LineWing la = wing[ja];
+        const LineCore ca = core[ja];
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
     }
 }
 
+// Contiguous share `part` of `parts` of the index range [j0, j1), in units of `unit` lines
+// (the last share also takes the remainder).
+__device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, int unit,
+                                         int & begin, int & end)
+{
+    const int units = (j1 - j0)/unit;
+    begin = j0 + (int)(((long long)units*part)/parts)*unit;
+    end = (part + 1 == parts) ? j1 : j0 + (int)(((long long)units*(part + 1))/parts)*unit;
+}
+
+// One 256-thread workgroup per tile.  Its four wavefronts own the SAME 64*P grid points and
+// split the tile's lines four ways (every cut-point range is quartered), so a tile is four
+// independent work items for the dispatcher instead of one; the four partial sums meet in
+// LDS and each wavefront finishes P/4 of the rows (pedestal, scaling, the one store of k).
 template <int P>
 __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
 {
+    __shared__ double partial[4][P][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int level = blockIdx.y;
-    const int tile = blockIdx.x*4 + wave;
+    // Workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous eighth
+    // of the spectrum so that neighbouring tiles (which share most of their lines) meet in
+    // the same L2.  Placement only changes speed.
+    const int per_xcd = (a.n_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
     if (tile >= a.n_tiles)
     {
         return;
@@ -152,11 +230,37 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         acc[p] = 0.;
     }
 
-    general_range<P>(wing, core, sc.lo, sc.a1, i0, i1, lane, v, acc);
-    fast_range<P>(wing, sc.a1, sc.c1, v, acc);
-    general_range<P>(wing, core, sc.c1, sc.c2, i0, i1, lane, v, acc);
-    fast_range<P>(wing, sc.c2, sc.a2, v, acc);
-    general_range<P>(wing, core, sc.a2, sc.hi, i0, i1, lane, v, acc);
+    // This wavefront's quarter of each of the five cut-point ranges.
+    GeneralList g;
+    int fa0, fa1, fb0, fb1, e;
+    share_of(sc.lo, sc.a1, wave, 4, 1, g.begin[0], e);
+    g.count[0] = e - g.begin[0];
+    share_of(sc.c1, sc.c2, wave, 4, 1, g.begin[1], e);
+    g.count[1] = e - g.begin[1];
+    share_of(sc.a2, sc.hi, wave, 4, 1, g.begin[2], e);
+    g.count[2] = e - g.begin[2];
+    share_of(sc.a1, sc.c1, wave, 4, 4, fa0, fa1);
+    share_of(sc.c2, sc.a2, wave, 4, 4, fb0, fb1);
+    // Left-over lines of the far-wing ranges (fewer than four each) take the general path.
+    g.begin[3] = fa0 + ((fa1 - fa0) & ~3);
+    g.count[3] = (fa1 - fa0) & 3;
+    g.begin[4] = fb0 + ((fb1 - fb0) & ~3);
+    g.count[4] = (fb1 - fb0) & 3;
+    if (!(a.ablate & 2))
+    {
+        fast_ranges<P>(wing, fa0, fa1, fb0, fb1, v, acc);
+    }
+    if (!(a.ablate & 1))
+    {
+        general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
+    }
+
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+    {
+        partial[wave][p][lane] = acc[p];
+    }
+    __syncthreads();
 
     double scale = 1.;
     if (a.scale_density)
@@ -164,13 +268,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         scale = a.levels[level].density;
     }
     double * __restrict__ out = a.k + (long long)level*a.level_stride;
-#pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int p = wave; p < P; p += 4)
     {
         const int i = i0 + p*64 + lane;
         if (i < a.n)
         {
-            double value = acc[p];
+            // Fixed order of the four partial sums: results do not depend on scheduling.
+            double value = (partial[0][p][lane] + partial[1][p][lane]) +
+                           (partial[2][p][lane] + partial[3][p][lane]);
             if (a.pedestal_cell != nullptr)
             {
                 // Sum of the pedestals of every line whose window holds point i

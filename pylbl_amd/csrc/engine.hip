@@ -127,6 +127,7 @@ struct lbl_engine
     int points_per_lane = 0;
     int timing = 0;
     long long workspace_bytes = 4ll << 30;
+    int ablate = 0;
 
     // Workspace (grown on demand, reused across calls).
     DeviceBuffer<LineWing> wing;
@@ -490,6 +491,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.dv = g.dv;
             args.scale_density = (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0;
             args.accumulate = (out_device && (rq.flags & LBL_ACCUMULATE)) ? 1 : 0;
+            args.ablate = engine->ablate;
 
             if (rq.remove_pedestal && n_lines > 0)
             {
@@ -502,7 +504,8 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
 
             engine->timed(kTimeAccumulate, [&] {
-                dim3 grid((unsigned)((n_tiles + 3)/4), (unsigned)count);
+                // One workgroup per tile, padded to a multiple of 8 for the XCD mapping.
+                dim3 grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
                 launch_accumulate(points, grid, stream, args);
             });
 
@@ -808,6 +811,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "timing" && (value == 0 || value == 1))
     {
         engine->timing = (int)value;
+    }
+    else if (key == "ablate" && value >= 0 && value <= 3)
+    {
+        engine->ablate = (int)value;    // timing diagnostics only: results are wrong when set
     }
     else if (key == "workspace_bytes" && value >= (1 << 20))
     {

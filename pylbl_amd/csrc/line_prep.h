@@ -54,11 +54,13 @@ struct alignas(32) LineWing
     int first, last;        // window [first, last] inclusive    spectra.c:48-62; empty if first > last
 };
 
-struct alignas(32) LineCore
+struct alignas(16) LineCore
 {
     double repwid;          // sqrt(ln2)/alpha                   voigt.c:13
     double y;               // repwid*gamma                      voigt.c:14
     double amp;             // S/sqrt(pi)*repwid                 voigt.c:188
+    double xlim0;           // far-wing limit                    voigt.c:34
+    double xlim1;           // w4 region-1 limit                 voigt.c:35-43, :48-53
     int core_first, core_last;  // grid indices that may fall inside |x| < xlim0 (conservative)
 };
 
@@ -69,7 +71,8 @@ constexpr int kEmptyLast = -0x3fffffff;
 __host__ __device__ inline void mark_empty(LineWing & w, LineCore & c)
 {
     w.centre = 0.; w.g2 = 1.; w.bl = 0.; w.first = kEmptyFirst; w.last = kEmptyLast;
-    c.repwid = 1.; c.y = 100.; c.amp = 0.; c.core_first = kEmptyFirst; c.core_last = kEmptyLast;
+    c.repwid = 1.; c.y = 100.; c.amp = 0.; c.xlim0 = 0.; c.xlim1 = 0.;
+    c.core_first = kEmptyFirst; c.core_last = kEmptyLast;
 }
 
 // status: 1 evaluated, 0 window right of the grid / empty, -1 not accepted by the range rule.
@@ -145,6 +148,10 @@ __host__ __device__ inline int prepare_line(const LevelScalars & lv, const GridS
     {
         // voigt.c:34: beyond xlim0 Doppler half-widths the profile is the Lorentz wing.
         const double xlim0 = sqrt(15100. + y*(40. - y*3.6));
+        double xlim1 = (y >= 8.425) ? 0. : sqrt(164. - y*(4.3 + y*1.8));
+        if (y <= 0.000001) xlim1 = xlim0;               // voigt.c:48-53
+        c.xlim0 = xlim0;
+        c.xlim1 = xlim1;
         const double reach = (xlim0/repwid)*(1. + 1.e-9);
         double lo = floor((centre - reach - (double)g.v0)*g.n_per_v) - 1.;
         double hi = floor((centre + reach - (double)g.v0)*g.n_per_v) + 2.;

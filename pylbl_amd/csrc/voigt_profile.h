@@ -27,21 +27,22 @@ __device__ __forceinline__ double rcp_newton(double t)
     return __builtin_fma(r, e, r);
 }
 
-// One far-wing line at one point.
-__device__ __forceinline__ double lorentz_one(double v, double centre, double g2, double bl)
+// One far-wing line at one point, added to `sum`.
+__device__ __forceinline__ double lorentz_one(double v, double centre, double g2, double bl,
+                                              double sum)
 {
     const double d = v - centre;
-    return bl*rcp_newton(__builtin_fma(d, d, g2));
+    return __builtin_fma(bl, rcp_newton(__builtin_fma(d, d, g2)), sum);
 }
 
-// Four far-wing lines at one point with a single reciprocal:
+// Four far-wing lines at one point with a single reciprocal, added to `sum`:
 //   sum b_i/t_i = N/(t1 t2 t3 t4).  Products stay far from over/underflow because
 //   t = d^2 + gamma^2 lies in [~1e-12, ~1e3] for every window the reference allows.
 __device__ __forceinline__ double lorentz_four(double v,
                                                double c1, double g1, double b1,
                                                double c2, double g2, double b2,
                                                double c3, double g3, double b3,
-                                               double c4, double g4, double b4)
+                                               double c4, double g4, double b4, double sum)
 {
     const double d1 = v - c1, d2 = v - c2, d3 = v - c3, d4 = v - c4;
     const double t1 = __builtin_fma(d1, d1, g1);
@@ -52,7 +53,7 @@ __device__ __forceinline__ double lorentz_four(double v,
     const double n34 = __builtin_fma(b3, t4, b4*t3);
     const double t12 = t1*t2, t34 = t3*t4;
     const double num = __builtin_fma(n12, t34, n34*t12);
-    return num*rcp_newton(t12*t34);
+    return __builtin_fma(num, rcp_newton(t12*t34), sum);
 }
 
 // K(x,y) for y < 70.55 exactly as voigt.c:74-187 selects and evaluates it.
