@@ -1,0 +1,154 @@
+"""CPU-only checks of the host side: database read side and fixtures, grid handling, the
+registry contract, and that the C-ABI library loads and exports every declared symbol."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from pylbl_amd import database, synthetic
+from pylbl_amd.errors import AliasNotFoundError, TipsDataNotFoundError
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/lbl_amd.h is exported by liblbl_amd.so (built by
+    __graft_entry__.build()); no compute call is made."""
+    import __graft_entry__
+    __graft_entry__.build()
+    from pylbl_amd import engine
+    header = (ROOT / "include" / "lbl_amd.h").read_text()
+    declared = set(re.findall(r"\b(lbl_[a-z_]+)\s*\(", header))
+    assert declared == set(engine.EXPORTED_SYMBOLS)
+    lib = engine.library()
+    for name in sorted(declared) + ["absorption"]:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.lbl_version()
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pylbl_amd import engine
+    from pylbl_amd.errors import EngineError
+    with pytest.raises(EngineError, match="no CPU fallback"):
+        engine.Engine(0)
+
+
+def test_database_round_trip(tmp_path):
+    """write_database uses the reference's DDL; the read side returns the rows in order
+    (pyLBL/database.py:350-395, absorption.c:69-70)."""
+    tables = [synthetic.line_table("H2O", 1., 200., num_lines=300, seed=1, tips_range=(150, 350)),
+              synthetic.line_table("CO2", 1., 200., num_lines=200, seed=2, tips_range=(150, 350))]
+    path = database.write_database(tmp_path / "lines.db", tables, aliases={"H2O": ["water"]})
+    db = database.Database(path)
+    assert db.path == path
+    assert db.molecules() == ["H2O", "CO2"]
+    for name, table in (("H2O", tables[0]), ("water", tables[0]), ("CO2", tables[1])):
+        got = db.line_table(name)
+        for column in database.LINE_COLUMNS:
+            assert np.array_equal(getattr(got, column), getattr(table, column))
+        assert np.array_equal(got.local_iso_id, table.local_iso_id)
+        assert np.array_equal(got.mass, table.mass)
+        assert np.array_equal(got.tips_data, table.tips_data)
+        assert np.array_equal(got.tips_temperature, table.tips_temperature)
+    formula, mass, transitions, tips = db.gas("CO2")
+    assert formula == "CO2" and mass == list(tables[1].mass)
+    assert transitions[5].nu == tables[1].nu[5] and transitions.sw.shape == (200,)
+    temperature, data = db.tips("H2O")
+    assert data.shape == (4, temperature.size)
+    # pyLBL/tips.py:26-39 twin.
+    q = tips.total_partition_function(279.54, 1)
+    j = int(279.54) - 150
+    expect = data_co2 = db.tips("CO2")[1][0]
+    assert q == pytest.approx(expect[j] + (expect[j+1] - expect[j])*0.54, rel=1e-12)
+    with pytest.raises(AliasNotFoundError):
+        db.line_table("XYZ")
+
+
+def test_database_without_tips_raises(tmp_path):
+    table = synthetic.line_table("N2O", 1., 50., num_lines=10, tips_range=(150, 350))
+    path = database.write_database(tmp_path / "no_tips.db", [table], with_tips=set())
+    with pytest.raises(TipsDataNotFoundError):
+        database.Database(path).line_table("N2O")
+
+
+def test_mass_slots_follow_hitran_counting():
+    """isoid 0 is the tenth isotopologue (spectral_database.c:119-123)."""
+    table = synthetic.line_table("O3", 1., 50., num_lines=10)
+    table.isoid = np.asarray([1, 2, 0, 4])
+    slots = table.mass_by_slot()
+    assert slots[0] == table.mass[0] and slots[9] == table.mass[2] and slots[2] == 0.
+
+
+def test_grid_arguments_match_reference_rounding():
+    """pyLBL/c_lib/gas_optics.py:61-63 on the reference's own test grids
+    (tests/conftest.py:43-50)."""
+    assert synthetic.grid_arguments(np.arange(1., 3250., 0.1)) == (1, 3251, 10)
+    assert synthetic.grid_arguments(np.arange(1., 3000., 1.)) == (1, 3000, 1)
+    assert synthetic.grid_arguments(np.arange(500., 800., 0.1)) == (500, 801, 10)
+    assert synthetic.grid_arguments(np.arange(1., 5000., 0.001)) == (1, 5001, 1000)
+
+
+def test_registry_contract():
+    """Same shape and failure mode as pyLBL/plugins.py / spectroscopy.py:118
+    (reference test: tests/test_spectroscopy.py:28-32)."""
+    from pylbl_amd import Gas, Spectroscopy, molecular_lines
+    assert molecular_lines["mi355x"] is Gas
+    atmos = synthetic.fixture_atmosphere()
+    grid = np.arange(1., 10., 1.)
+    with pytest.raises(KeyError):
+        Spectroscopy(atmos, grid, None, lines_backend="not-a-backend")
+    spec = Spectroscopy(atmos, grid, None)
+    assert spec.output.dim_sizes == [4, 3, 9]
+    target = {}
+    from pylbl_amd import register
+    assert register("mi355x", into=target)["mi355x"] is Gas
+
+
+def test_number_density():
+    from pylbl_amd import number_density
+    assert number_density(288.99, 98388., 1.) == pytest.approx(98388./(1.38064852e-23*288.99))
+
+
+def test_synthetic_tables_are_deterministic_and_sorted():
+    a = synthetic.line_table("CO2", 1., 100., num_lines=500)
+    b = synthetic.line_table("CO2", 1., 100., num_lines=500)
+    assert np.array_equal(a.nu, b.nu) and np.all(np.diff(a.nu) >= 0)
+    assert a.tips_data.dtype == np.float64
+    assert np.array_equal(a.tips_data, a.tips_data.astype(np.float32).astype(np.float64))
+    atmos = synthetic.standard_atmosphere(64)
+    assert atmos.p[0] == pytest.approx(101325.) and atmos.p[-1] == pytest.approx(10.)
+    assert np.all(atmos.t >= 180.) and set(atmos.vmr) == set(synthetic.MOLECULE_IDS)
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """The C restatement is clean under ASan/UBSan on a clipped, pedestal-on case
+    (sanitizers on the CPU build only)."""
+    import subprocess, sys, textwrap
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "asan"], check=True,
+                   stdout=subprocess.DEVNULL)
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {str(ROOT)!r})
+        from oracle import oracle
+        oracle.PORT_LIB = oracle.HERE / "liblbl_oracle_asan.so"
+        from tests import golden_io
+        import numpy as np
+        table, cases = golden_io.load_group("clipping")
+        for case in cases:
+            k, _ = oracle.absorption_port(table, case.temperature, case.pressure, case.vmr,
+                                          case.v0, case.vn, case.n_per_v, cut_off=case.cut_off,
+                                          remove_pedestal=case.remove_pedestal)
+            assert np.array_equal(k, case.k)
+        print("clean")
+    """)
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True,
+                             text=True).stdout.strip()
+    result = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                            env={"LD_PRELOAD": libasan, "ASAN_OPTIONS": "detect_leaks=0",
+                                 "PATH": "/usr/bin:/bin"})
+    assert "clean" in result.stdout, result.stderr[-2000:]
+    assert "runtime error" not in result.stderr and "AddressSanitizer" not in result.stderr
