@@ -1,0 +1,239 @@
+"""The drop-in surface on a real GPU: Gas over a database file, the Spectroscopy lines slot,
+the same-signature C entry, device-resident outputs, and size-independent properties at the
+benchmark's full grid (5 M points)."""
+from ctypes import c_char_p, c_double, c_int
+import numpy as np
+import pytest
+
+from pylbl_amd import synthetic
+from pylbl_amd.database import Database, write_database
+from tests import golden_io
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_database(tmp_path_factory):
+    tables = [synthetic.line_table("H2O", 1., 130., num_lines=400, seed=41, tips_range=(150, 400)),
+              synthetic.line_table("CO2", 1., 130., num_lines=600, seed=42, tips_range=(150, 400)),
+              synthetic.line_table("N2O", 1., 130., num_lines=50, seed=43, tips_range=(150, 400))]
+    path = tmp_path_factory.mktemp("db") / "lines.db"
+    write_database(path, tables, with_tips={"H2O", "CO2"})
+    return Database(str(path)), {t.formula: t for t in tables}
+
+
+def check(k, k_ref, n_per_v, remove_pedestal, label):
+    case = golden_io.Case("api", 0, 0, 0, 0, 0, 0, n_per_v, 25, remove_pedestal, None, 0)
+    if remove_pedestal:
+        tol = golden_io.pedestal_tolerance(k_ref, n_per_v, 25, 1.e-6) + 1e-300
+        assert np.max(np.abs(k - k_ref)/tol) <= 1., label
+    else:
+        np.testing.assert_allclose(k, k_ref, rtol=1.e-6, atol=0., err_msg=label)
+
+
+def test_gas_over_database_file(small_database, oracle):
+    """Same constructor and call as the reference's test (tests/test_gas_optics.py:7-16)."""
+    from pylbl_amd import Gas
+    db, tables = small_database
+    grid = np.arange(1., 100., 0.05)
+    v0, vn, npv = synthetic.grid_arguments(grid)
+    gas = Gas(db, "H2O")
+    assert gas.database == db.path and gas.formula == "H2O"
+    for ped in (False, True):
+        k = gas.absorption_coefficient(temperature=288.99, pressure=98388.,
+                                       volume_mixing_ratio=6.637074e-3, grid=grid,
+                                       remove_pedestal=ped)
+        assert k.shape == ((vn - v0)*npv,) and k.size >= grid.size
+        k_ref, _ = oracle.absorption_port(tables["H2O"], 288.99, 98388., 6.637074e-3, v0, vn,
+                                          npv, remove_pedestal=ped)
+        check(k, k_ref, npv, ped, f"Gas H2O ped={ped}")
+    # No TIPS rows: rc 0 and zeros in the reference (absorption.c:53-59).
+    k = Gas(db, "N2O").absorption_coefficient(288.99, 98388., 3.2e-7, grid)
+    assert k.shape == ((vn - v0)*npv,) and not k.any()
+    # Unknown alias: the reference raises ValueError from the return-code hook
+    # (gas_optics.py:15-26, spectral_database.c:152-156).
+    with pytest.raises(ValueError):
+        Gas(db, "XYZ").absorption_coefficient(288.99, 98388., 1e-6, grid)
+
+
+def test_spectroscopy_lines_slot(small_database, oracle):
+    """beta[level, 0, :] = n k[:grid.size] for every gas and level
+    (pyLBL/spectroscopy.py:166-191), three output formats (:208-235)."""
+    from pylbl_amd import Spectroscopy, number_density
+    db, tables = small_database
+    full = synthetic.fixture_atmosphere()
+    atmos = synthetic.Atmos(p=full.p, t=full.t, vmr={k: full.vmr[k] for k in ("H2O", "CO2", "N2O")})
+    grid = np.arange(1., 90., 0.1)
+    v0, vn, npv = synthetic.grid_arguments(grid)
+    spec = Spectroscopy(atmos, grid, db)
+    assert spec.list_molecules() == ["H2O", "CO2", "N2O"]
+    for ped in (True, False):
+        out = spec.compute_absorption(output_format="all", remove_pedestal=None if ped else False)
+        assert list(out["mechanism"]) == ["lines", "continuum", "cross_section"]
+        assert np.array_equal(out["wavenumber"], grid)
+        for formula in ("H2O", "CO2"):
+            beta = np.asarray(out[f"{formula}_absorption"])
+            assert beta.shape == (4, 3, grid.size)
+            assert not beta[:, 1:, :].any()
+            for level in range(4):
+                t, p, x = atmos.t[level], atmos.p[level], atmos.vmr[formula][level]
+                k_ref, _ = oracle.absorption_port(tables[formula], t, p, x, v0, vn, npv,
+                                                  remove_pedestal=ped)
+                ref = number_density(t, p, x)*k_ref[:grid.size]
+                check(beta[level, 0], ref, npv, ped, f"{formula} level {level} ped={ped}")
+        assert not np.asarray(out["N2O_absorption"]).any()
+    per_gas = spec.compute_absorption(output_format="gas", remove_pedestal=False)
+    total = spec.compute_absorption(output_format="total", remove_pedestal=False)
+    assert np.asarray(per_gas["H2O_absorption"]).shape == (4, grid.size)
+    np.testing.assert_allclose(np.asarray(total["absorption"]),
+                               np.asarray(per_gas["H2O_absorption"]) +
+                               np.asarray(per_gas["CO2_absorption"]), rtol=1e-14)
+
+
+def test_same_signature_c_entry(small_database, oracle):
+    """lbl_absorption / absorption: the reference's 11-argument call
+    (absorption.c:19-30) driven exactly like gas_optics.py:61-91."""
+    from numpy.ctypeslib import ndpointer
+    from pylbl_amd import engine
+    db, tables = small_database
+    lib = engine.library()
+    for name in ("lbl_absorption", "absorption"):
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = 3*[c_double] + 3*[c_int] + [ndpointer(c_double, flags="C_CONTIGUOUS")] + \
+            2*[c_char_p] + 2*[c_int]
+        v0, vn, npv = 1, 101, 10
+        for ped in (0, 1):
+            k = np.full((vn - v0)*npv, 7.)
+            rc = fn(98388., 288.99, 3.6e-4, v0, vn, npv, k, db.path.encode(), b"CO2", 25, ped)
+            assert rc == 0
+            k_ref, _ = oracle.absorption_port(tables["CO2"], 288.99, 98388., 3.6e-4, v0, vn, npv,
+                                              remove_pedestal=bool(ped))
+            check(k, k_ref, npv, bool(ped), f"{name} ped={ped}")
+        k = np.full((vn - v0)*npv, 7.)
+        assert fn(98388., 288.99, 3.2e-7, v0, vn, npv, k, db.path.encode(), b"N2O", 25, 0) == 0
+        assert not k.any()                                  # no TIPS rows: zeros, rc 0
+        assert fn(98388., 288.99, 3.2e-7, v0, vn, npv, k, db.path.encode(), b"XYZ", 25, 0) == 1
+
+
+def test_device_output_scale_and_accumulate(oracle):
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    from pylbl_amd import number_density
+    e = Engine(0)
+    a = synthetic.line_table("H2O", 1., 90., num_lines=150, seed=51, tips_range=(150, 400))
+    b = synthetic.line_table("CO2", 1., 90., num_lines=250, seed=52, tips_range=(150, 400))
+    ha, hb = e.load(a), e.load(b)
+    t, p = np.asarray([288.99, 220.]), np.asarray([98388., 5000.])
+    xa, xb = np.asarray([6e-3, 4e-6]), np.asarray([3.6e-4, 3.6e-4])
+    v0, vn, npv = 1, 61, 25
+    out = DeviceSpectra(e, 2, (vn - v0)*npv)
+    e.compute(ha, t, p, xa, v0, vn, npv, out=out, scale_density=True)
+    e.compute(hb, t, p, xb, v0, vn, npv, out=out, scale_density=True, accumulate=True)
+    total = out.to_host()
+    for level in range(2):
+        ka, _ = oracle.absorption_port(a, t[level], p[level], xa[level], v0, vn, npv)
+        kb, _ = oracle.absorption_port(b, t[level], p[level], xb[level], v0, vn, npv)
+        ref = number_density(t[level], p[level], xa[level])*ka + \
+            number_density(t[level], p[level], xb[level])*kb
+        np.testing.assert_allclose(total[level], ref, rtol=1e-6)
+    out.free()
+    e.close()
+
+
+def test_error_paths():
+    from pylbl_amd.engine import Engine
+    from pylbl_amd.errors import EngineError
+    e = Engine(0)
+    table = synthetic.line_table("H2O", 1., 90., num_lines=20, seed=1, tips_range=(200, 350))
+    h = e.load(table)
+    with pytest.raises(EngineError, match="partition-function"):
+        e.compute(h, 150., 1000., 1e-3, 1, 50, 10)          # T below the TIPS table
+    with pytest.raises(EngineError):
+        e.compute(h, 250., 1000., 1e-3, 50, 50, 10)         # empty grid
+    with pytest.raises(EngineError):
+        e.compute(99, 250., 1000., 1e-3, 1, 50, 10)         # unknown handle
+    bad = synthetic.line_table("H2O", 1., 90., num_lines=20, seed=1, tips_range=(200, 350))
+    bad.local_iso_id[3] = 7                                   # no mass / TIPS row for iso 7
+    with pytest.raises(EngineError, match="local_iso_id"):
+        e.load(bad)
+    k = e.compute(h, 250., 1000., 1e-3, 1, 50, 10)           # still usable afterwards
+    assert k.shape == (1, 490) and k.any()
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE target workload: H2O + CO2, grid 1-5000 cm-1 at 0.001 cm-1."""
+    from pylbl_amd.engine import Engine
+    e = Engine(0)
+    tables = {f: synthetic.line_table(f, 1., 5000.) for f in ("H2O", "CO2")}
+    handles = {f: e.load(t) for f, t in tables.items()}
+    yield e, tables, handles
+    e.close()
+
+
+def test_full_size_windows_against_oracle(full_size, oracle):
+    """Grid points only see lines within cut_off+1 cm-1, so narrow sub-grids computed by the
+    oracle must reproduce the matching slices of the 5 M-point spectrum."""
+    e, tables, handles = full_size
+    t, p, x = 288.99, 98388., {"H2O": 6.637074e-3, "CO2": 3.5999e-4}
+    v0, vn, npv = 1, 5001, 1000
+    for formula in ("H2O", "CO2"):
+        k, evals = e.compute(handles[formula], t, p, x[formula], v0, vn, npv, want_evals=True)
+        k = k[0]
+        table = tables[formula]
+        centre = table.nu + p*9.86923e-6*table.delta_air
+        first = np.clip((np.floor(centre) - 25 - v0)*npv, 0, None)
+        last = np.clip((np.floor(centre) + 26 - v0)*npv, None, (vn - v0)*npv - 1)
+        keep = first < (vn - v0)*npv
+        assert evals == int(np.sum((last - first + 1)[keep]))
+        for lo in (1, 667, 2349, 4998):
+            hi = lo + 2
+            # Oracle on [lo-2, hi+2] (clipped to the grid) with exactly the rows its range
+            # rule accepts; only the interior [lo, hi) is compared, so rows a hair outside
+            # the sub-grid's range cannot matter.
+            g0, g1 = max(lo - 2, v0), min(hi + 2, vn)
+            near = table.subset((table.nu >= g0 - 26.) & (table.nu <= g1 + 26.))
+            k_ref, _ = oracle.absorption_port(near, t, p, x[formula], g0, g1, npv)
+            k_ref = k_ref[(lo - g0)*npv:(hi - g0)*npv]
+            piece = k[(lo - v0)*npv:(hi - v0)*npv]
+            np.testing.assert_allclose(piece, k_ref, rtol=1e-6, err_msg=f"{formula} {lo}")
+
+
+def test_full_size_linearity_additivity_determinism(full_size):
+    e, tables, handles = full_size
+    t, p, x = 250., 20000., 1e-3
+    v0, vn, npv = 1, 5001, 1000
+    table = tables["H2O"]
+    k = e.compute(handles["H2O"], t, p, x, v0, vn, npv)[0]
+    assert np.array_equal(k, e.compute(handles["H2O"], t, p, x, v0, vn, npv)[0])  # bitwise
+    assert np.all(k > 0.) and np.all(np.isfinite(k))
+    # Doubling every line strength doubles the spectrum (a power of two: exactly).
+    doubled = table.subset(np.ones(table.num_lines, bool))
+    doubled.sw = 2.*table.sw
+    h2 = e.load(doubled)
+    assert np.array_equal(e.compute(h2, t, p, x, v0, vn, npv)[0], 2.*k)
+    e.free(h2)
+    # Splitting the table in two and adding the spectra gives the same sum.
+    odd = np.arange(table.num_lines) % 2 == 1
+    ha, hb = e.load(table.subset(odd)), e.load(table.subset(~odd))
+    parts = e.compute(ha, t, p, x, v0, vn, npv)[0] + e.compute(hb, t, p, x, v0, vn, npv)[0]
+    np.testing.assert_allclose(parts, k, rtol=1e-12)
+    e.free(ha)
+    e.free(hb)
+
+
+def test_full_size_pedestal_properties(full_size):
+    """With the pedestal removed the spectrum stays >= 0 up to rounding, is <= the plain
+    one, and levels in a batch do not influence each other."""
+    e, tables, handles = full_size
+    atmos = synthetic.fixture_atmosphere()
+    v0, vn, npv = 1, 5001, 1000
+    plain = e.compute(handles["CO2"], atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv)
+    ped = e.compute(handles["CO2"], atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
+                    remove_pedestal=True)
+    assert np.all(ped <= plain*(1. + 1e-12))
+    assert np.all(ped >= -1e-9*plain.max(axis=1, keepdims=True))
+    single = e.compute(handles["CO2"], atmos.t[2], atmos.p[2], atmos.vmr["CO2"][2], v0, vn, npv,
+                       remove_pedestal=True)[0]
+    assert np.array_equal(single, ped[2])
