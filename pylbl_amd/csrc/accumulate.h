@@ -28,6 +28,38 @@
 
 namespace lbl {
 
+// How the grid is cut into tiles of at most 64*P points.  When the points per wavenumber
+// allow it (little padding), tiles are aligned to the 1 cm-1 cells: line windows begin and
+// end on integer wavenumbers (spectra.c:48-62), so an aligned tile is never cut by a window
+// edge and every overlapping line covers it completely (bar the single closing point).
+struct Tiling
+{
+    int aligned;        // 1: `per_cell` tiles of `length` points inside every 1 cm-1 cell
+    int per_cell;
+    int length;         // points per tile (<= 64*P)
+    int n_tiles;
+};
+
+__host__ __device__ inline void tile_bounds(const Tiling & t, int tile, int n_per_v, int n,
+                                            long long & i0, long long & i1)
+{
+    if (t.aligned)
+    {
+        const int cell = tile/t.per_cell;
+        const int sub = tile - cell*t.per_cell;
+        i0 = (long long)cell*n_per_v + (long long)sub*t.length;
+        i1 = i0 + t.length - 1;
+        const long long cell_end = (long long)(cell + 1)*n_per_v - 1;
+        if (i1 > cell_end) i1 = cell_end;
+    }
+    else
+    {
+        i0 = (long long)tile*t.length;
+        i1 = i0 + t.length - 1;
+    }
+    if (i1 > n - 1) i1 = n - 1;
+}
+
 struct alignas(32) TileSchedule
 {
     int lo, a1, c1, c2, a2, hi;
@@ -46,6 +78,7 @@ struct AccumulateArgs
     double * k;                     // [levels][level_stride]
     long long level_stride;
     long long n_lines;
+    Tiling tiling;
     int n_tiles;
     int n;                          // grid points
     int v0, n_per_v;
@@ -112,24 +145,35 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
         const int i = r0 + lane;
         const bool inside = (i >= l.first) && (i <= l.last);
         const double d = v[p] - l.centre;
-        // voigt.c:82 / :24 in wavenumber units.
-        double value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-        if (!(c.core_last < r0 || c.core_first > r1))
+        double value;
+        if (c.core_last < r0 || c.core_first > r1)
+        {
+            // voigt.c:82 / :24 in wavenumber units: the whole row is in the far wing.
+            value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+        }
+        else
         {
             const double xi = d*c.repwid;               // voigt.c:76
             const double abx = fabs(xi);
             const double xq = abx*abx;
-            if (abx < c.xlim0)
+            const bool far = abx >= c.xlim0;
+            const bool mid = !far && abx >= c.xlim1;
+            value = 0.;
+            if (__any(far))
             {
-                if (abx >= c.xlim1)
-                {
-                    // voigt.c:95-96: buf = rsqrpi/(d0 + xq(d2 + xq)) * y * (a0 + xq)
-                    value = r1_scale*(a0 + xq)*rcp_newton(d0 + xq*(d2 + xq));
-                }
-                else
-                {
-                    value = c.amp*wells_profile(xi, c.y);
-                }
+                const double wing = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                value = far ? wing : value;
+            }
+            if (__any(mid))
+            {
+                // voigt.c:95-96: buf = rsqrpi/(d0 + xq(d2 + xq)) * y * (a0 + xq)
+                const double w4 = r1_scale*(a0 + xq)*
+                                  rcp_newton(__builtin_fma(xq, d2 + xq, d0));
+                value = mid ? w4 : value;
+            }
+            if (!far && !mid)
+            {
+                value = c.amp*wells_profile(xi, c.y);
             }
         }
         acc[p] += inside ? value : 0.;
@@ -212,9 +256,9 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     {
         return;
     }
-    const int i0 = tile*(64*P);
-    int i1 = i0 + 64*P - 1;
-    if (i1 > a.n - 1) i1 = a.n - 1;
+    long long first_point, last_point;
+    tile_bounds(a.tiling, tile, a.n_per_v, a.n, first_point, last_point);
+    const int i0 = (int)first_point, i1 = (int)last_point;
     const TileSchedule sc = a.schedule[(long long)level*a.n_tiles + tile];
     const LineWing * __restrict__ wing = a.wing + (long long)level*a.n_lines;
     const LineCore * __restrict__ core = a.core + (long long)level*a.n_lines;
@@ -271,7 +315,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     for (int p = wave; p < P; p += 4)
     {
         const int i = i0 + p*64 + lane;
-        if (i < a.n)
+        if (i <= i1)
         {
             // Fixed order of the four partial sums: results do not depend on scheduling.
             double value = (partial[0][p][lane] + partial[1][p][lane]) +

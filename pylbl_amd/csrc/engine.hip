@@ -113,14 +113,75 @@ struct Molecule
 
 enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3 };
 
+// One in-flight compute call: its own pair of streams and its own workspace, so that
+// several molecules can be in the pipeline at once (the serial pedestal chain of one
+// overlaps the accumulate kernels of the others, and its own).
+struct Lane
+{
+    hipStream_t main = nullptr;     // prepare, schedule, accumulate, apply, copies
+    hipStream_t side = nullptr;     // the pedestal pre-pass
+    hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
+    bool levels_in_flight = false;
+    DeviceBuffer<LineWing> wing;
+    DeviceBuffer<LineCore> core;
+    DeviceBuffer<TileSchedule> schedule;
+    DeviceBuffer<LevelScalars> levels;
+    DeviceBuffer<double> staging;   // spectra on their way to host memory
+    DeviceBuffer<double> raw;       // un-pedestalled sums when the output must be added to
+    DeviceBuffer<double> derived;
+    DeviceBuffer<unsigned long long> evals;
+    PedestalWorkspace pedestal;
+    LevelScalars * pinned_levels = nullptr;
+    size_t pinned_capacity = 0;
+
+    void create()
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
+    }
+    void drain()
+    {
+        if (main != nullptr) (void)hipStreamSynchronize(main);
+        if (side != nullptr) (void)hipStreamSynchronize(side);
+    }
+    void destroy()
+    {
+        drain();
+        if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
+        pinned_levels = nullptr;
+        if (prepared != nullptr) (void)hipEventDestroy(prepared);
+        if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
+        if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
+        if (main != nullptr) (void)hipStreamDestroy(main);
+        if (side != nullptr) (void)hipStreamDestroy(side);
+        main = side = nullptr;
+    }
+    void reserve_pinned(size_t count)
+    {
+        if (count <= pinned_capacity) return;
+        if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
+        pinned_levels = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_levels),
+                              count*sizeof(LevelScalars), hipHostMallocDefault));
+        pinned_capacity = count;
+    }
+};
+
+constexpr int kLanes = 8;
+
 }  // namespace
 
 struct lbl_engine
 {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
     std::string error;
     std::vector<std::unique_ptr<Molecule>> molecules;
+    Lane lanes[kLanes];
+    unsigned next_lane = 0;
 
     // Options.
     int prep = LBL_PREP_DEVICE;
@@ -128,18 +189,8 @@ struct lbl_engine
     int timing = 0;
     long long workspace_bytes = 4ll << 30;
     int ablate = 0;
-
-    // Workspace (grown on demand, reused across calls).
-    DeviceBuffer<LineWing> wing;
-    DeviceBuffer<LineCore> core;
-    DeviceBuffer<TileSchedule> schedule;
-    DeviceBuffer<LevelScalars> levels;
-    DeviceBuffer<double> staging;
-    DeviceBuffer<double> derived;
-    DeviceBuffer<unsigned long long> evals;
-    PedestalWorkspace pedestal;
-    LevelScalars * pinned_levels = nullptr;
-    size_t pinned_capacity = 0;
+    int aligned_tiles = 0;          // measured: no gain at 0.001 cm-1
+    int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind; };
@@ -162,7 +213,7 @@ struct lbl_engine
     }
 
     template <typename F>
-    void timed(int kind, F && launch)
+    void timed(int kind, hipStream_t on, F && launch)
     {
         if (!timing)
         {
@@ -170,9 +221,9 @@ struct lbl_engine
             return;
         }
         Span s{take_event(), take_event(), kind};
-        HIP_TRY(hipEventRecord(s.begin, stream));
+        HIP_TRY(hipEventRecord(s.begin, on));
         launch();
-        HIP_TRY(hipEventRecord(s.end, stream));
+        HIP_TRY(hipEventRecord(s.end, on));
         spans.push_back(s);
         if (spans.size() >= 4096) drain_spans();
     }
@@ -192,14 +243,9 @@ struct lbl_engine
         spans.clear();
     }
 
-    void reserve_pinned(size_t count)
+    void drain_lanes()
     {
-        if (count <= pinned_capacity) return;
-        if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
-        pinned_levels = nullptr;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_levels),
-                              count*sizeof(LevelScalars), hipHostMallocDefault));
-        pinned_capacity = count;
+        for (auto & lane : lanes) lane.drain();
     }
 };
 
@@ -288,14 +334,39 @@ int first_row_out_of_range(const Molecule & m, double nu_min, double nu_max)
     return (int)nu.size();
 }
 
-int pick_points_per_lane(const lbl_engine * engine, int n_per_v)
+// Points per lane P (tile = 64*P points) and the tiling.  Cell-aligned tiles are used when
+// they waste at most 6 % of the lanes on padding.
+int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & tiling)
 {
-    const int p = engine->points_per_lane;
-    if (p == 1 || p == 2 || p == 4 || p == 8) return p;
-    if (n_per_v >= 400) return 8;
-    if (n_per_v >= 100) return 4;
-    if (n_per_v >= 20) return 2;
-    return 1;
+    const int forced = engine->points_per_lane;
+    const bool is_forced = forced == 1 || forced == 2 || forced == 4 || forced == 8;
+    const int candidates[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c)
+    {
+        const int p = is_forced ? forced : candidates[c];
+        const int width = 64*p;
+        const int per_cell = (n_per_v + width - 1)/width;
+        const double waste = (double)per_cell*width/n_per_v - 1.;
+        if (engine->aligned_tiles && waste <= 0.06)
+        {
+            tiling.aligned = 1;
+            tiling.per_cell = per_cell;
+            tiling.length = (n_per_v + per_cell - 1)/per_cell;
+            tiling.n_tiles = (int)(n/n_per_v)*per_cell;
+            return p;
+        }
+        if (is_forced) break;
+    }
+    int p = forced;
+    if (!is_forced)
+    {
+        p = n_per_v >= 400 ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
+    }
+    tiling.aligned = 0;
+    tiling.per_cell = 0;
+    tiling.length = 64*p;
+    tiling.n_tiles = (int)((n + tiling.length - 1)/tiling.length);
+    return p;
 }
 
 void launch_accumulate(int points, dim3 grid, hipStream_t stream, const AccumulateArgs & args)
@@ -358,9 +429,9 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
     rule.nu_max = rq.vn + rq.cut_off + 1;
     rule.row_limit = first_row_out_of_range(*m, rule.nu_min, rule.nu_max);
 
-    const int points = pick_points_per_lane(engine, rq.n_per_v);
-    const int tile_points = 64*points;
-    const int n_tiles = (int)((n_long + tile_points - 1)/tile_points);
+    Tiling tiling;
+    const int points = pick_tiling(engine, rq.n_per_v, n_long, tiling);
+    const int n_tiles = tiling.n_tiles;
     const int n_cells = rq.vn - rq.v0;
     const bool out_device = (rq.flags & LBL_OUT_DEVICE) != 0;
     const bool want_k = rq.k != nullptr;
@@ -369,7 +440,18 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
-        hipStream_t stream = engine->stream;
+        // Asynchronous calls alternate between the two lanes; anything that adds into its
+        // output, or that the caller waits for, takes lane 0 with the other lane idle.
+        // Only calls with a pedestal gain from sharing the GPU (their serial chain leaves
+        // it almost idle); plain calls run back to back on lane 0.
+        const bool alternate = (rq.flags & LBL_ASYNC) && !(rq.flags & LBL_ACCUMULATE) &&
+                               want_k && rq.derived == nullptr && rq.remove_pedestal;
+        Lane & lane = engine->lanes[alternate ? (engine->next_lane++ % kLanes) : 0];
+        if (!alternate)
+        {
+            for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+        }
+        hipStream_t stream = lane.main;
 
         // Levels per pass, bounded by the workspace budget.
         const long long per_level = n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
@@ -380,18 +462,27 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         chunk = std::min<long long>(chunk, rq.n_levels);
         if (chunk > 65535) chunk = 65535;
 
-        engine->reserve_pinned((size_t)chunk);
-        engine->levels.reserve((size_t)chunk);
-        engine->wing.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
-        engine->core.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
-        engine->schedule.reserve((size_t)(chunk*n_tiles));
-        if (want_k && !out_device) engine->staging.reserve((size_t)(chunk*n_long));
+        const bool with_pedestal = rq.remove_pedestal && n_lines > 0 && want_k;
+        const bool add_into = (rq.flags & LBL_ACCUMULATE) != 0;
+        if (lane.levels_in_flight)
+        {
+            // The previous call on this lane may still be copying from the pinned block.
+            HIP_TRY(hipEventSynchronize(lane.levels_copied));
+            lane.levels_in_flight = false;
+        }
+        lane.reserve_pinned((size_t)chunk);
+        lane.levels.reserve((size_t)chunk);
+        lane.wing.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
+        lane.core.reserve((size_t)(chunk*std::max(n_lines, 1ll)));
+        lane.schedule.reserve((size_t)(chunk*n_tiles));
+        if (want_k && !out_device) lane.staging.reserve((size_t)(chunk*n_long));
+        if (with_pedestal && out_device && add_into) lane.raw.reserve((size_t)(chunk*n_long));
         if (rq.evals != nullptr)
         {
-            engine->evals.reserve(1);
-            HIP_TRY(hipMemsetAsync(engine->evals.data, 0, sizeof(unsigned long long), stream));
+            lane.evals.reserve(1);
+            HIP_TRY(hipMemsetAsync(lane.evals.data, 0, sizeof(unsigned long long), stream));
         }
-        if (rq.derived != nullptr) engine->derived.reserve((size_t)(std::max(n_lines, 1ll)*8));
+        if (rq.derived != nullptr) lane.derived.reserve((size_t)(std::max(n_lines, 1ll)*8));
 
         std::vector<LineWing> host_wing;
         std::vector<LineCore> host_core;
@@ -406,14 +497,16 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             {
                 std::string why;
                 if (!fill_level(*m, rq.temperature[base + l], rq.pressure[base + l],
-                                rq.vmr[base + l], engine->pinned_levels[l], why))
+                                rq.vmr[base + l], lane.pinned_levels[l], why))
                 {
                     return fail(engine, LBL_OUT_OF_RANGE,
                                 "level " + std::to_string(base + l) + ": " + why);
                 }
             }
-            HIP_TRY(hipMemcpyAsync(engine->levels.data, engine->pinned_levels,
+            HIP_TRY(hipMemcpyAsync(lane.levels.data, lane.pinned_levels,
                                    count*sizeof(LevelScalars), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipEventRecord(lane.levels_copied, stream));
+            lane.levels_in_flight = true;
 
             // K1: per-line scalars.
             if (n_lines > 0 && engine->prep == LBL_PREP_HOST)
@@ -431,18 +524,18 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                                      ? host_derived.data() + j*8 : nullptr;
                         LineWing & w = host_wing[(size_t)(l*n_lines + j)];
                         const int status = prepare_line(
-                            engine->pinned_levels[l], g, m->column[0][j], m->column[1][j],
+                            lane.pinned_levels[l], g, m->column[0][j], m->column[1][j],
                             m->column[2][j], m->column[3][j], m->column[4][j], m->column[5][j],
                             m->column[6][j], m->iso_slot[j], ok, w,
                             host_core[(size_t)(l*n_lines + j)], d);
                         if (status == 1 && w.last >= w.first) total += w.last - w.first + 1;
                     }
                 }
-                engine->timed(kTimePrepare, [&] {
-                    HIP_TRY(hipMemcpyAsync(engine->wing.data, host_wing.data(),
+                engine->timed(kTimePrepare, stream, [&] {
+                    HIP_TRY(hipMemcpyAsync(lane.wing.data, host_wing.data(),
                                            host_wing.size()*sizeof(LineWing),
                                            hipMemcpyHostToDevice, stream));
-                    HIP_TRY(hipMemcpyAsync(engine->core.data, host_core.data(),
+                    HIP_TRY(hipMemcpyAsync(lane.core.data, host_core.data(),
                                            host_core.size()*sizeof(LineCore),
                                            hipMemcpyHostToDevice, stream));
                 });
@@ -451,69 +544,105 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
             else if (n_lines > 0)
             {
-                engine->timed(kTimePrepare, [&] {
+                engine->timed(kTimePrepare, stream, [&] {
                     dim3 grid((unsigned)((n_lines + 255)/256), (unsigned)count);
                     hipLaunchKernelGGL(prepare_kernel, grid, dim3(256), 0, stream, m->view(),
-                                       engine->levels.data, g, rule, engine->wing.data,
-                                       engine->core.data,
-                                       rq.derived != nullptr ? engine->derived.data : nullptr,
-                                       rq.evals != nullptr ? engine->evals.data : nullptr);
+                                       lane.levels.data, g, rule, lane.wing.data,
+                                       lane.core.data,
+                                       rq.derived != nullptr ? lane.derived.data : nullptr,
+                                       rq.evals != nullptr ? lane.evals.data : nullptr);
                     HIP_TRY(hipGetLastError());
                 });
             }
 
             if (!want_k) continue;
 
+            if (with_pedestal)
+            {
+                HIP_TRY(hipEventRecord(lane.prepared, stream));
+            }
+
             // Tile cut points.
-            engine->timed(kTimeSchedule, [&] {
+            engine->timed(kTimeSchedule, stream, [&] {
                 dim3 grid((unsigned)((n_tiles + 255)/256), (unsigned)count);
                 hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, stream,
-                                   m->d_column[0].data, (int)n_lines, engine->levels.data, g,
-                                   tile_points, n_tiles, engine->schedule.data);
+                                   m->d_column[0].data, (int)n_lines, lane.levels.data, g,
+                                   tiling, lane.schedule.data);
                 HIP_TRY(hipGetLastError());
             });
 
+            // Where the spectra of this pass end up, and where the accumulate kernel writes.
+            double * target = out_device ? rq.k + base*stride : lane.staging.data;
+            const long long target_stride = out_device ? stride : n_long;
+            double * sums = target;
+            long long sums_stride = target_stride;
+            if (with_pedestal && out_device && add_into)
+            {
+                sums = lane.raw.data;
+                sums_stride = n_long;
+            }
+
             AccumulateArgs args;
-            args.wing = engine->wing.data;
-            args.core = engine->core.data;
-            args.schedule = engine->schedule.data;
-            args.levels = engine->levels.data;
+            args.wing = lane.wing.data;
+            args.core = lane.core.data;
+            args.schedule = lane.schedule.data;
+            args.levels = lane.levels.data;
             args.pedestal_cell = nullptr;
             args.pedestal_point = nullptr;
             args.n_cells = n_cells;
-            args.level_stride = out_device ? stride : n_long;
-            args.k = out_device ? rq.k + base*stride : engine->staging.data;
+            args.level_stride = sums_stride;
+            args.k = sums;
             args.n_lines = n_lines;
+            args.tiling = tiling;
             args.n_tiles = n_tiles;
             args.n = g.n;
             args.v0 = g.v0;
             args.n_per_v = g.n_per_v;
             args.dv = g.dv;
-            args.scale_density = (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0;
-            args.accumulate = (out_device && (rq.flags & LBL_ACCUMULATE)) ? 1 : 0;
+            // With a pedestal the kernel stores plain sums; pedestal_apply_kernel finishes.
+            args.scale_density = (!with_pedestal && (rq.flags & LBL_SCALE_DENSITY)) ? 1 : 0;
+            args.accumulate = (!with_pedestal && out_device && add_into) ? 1 : 0;
             args.ablate = engine->ablate;
 
-            if (rq.remove_pedestal && n_lines > 0)
-            {
-                engine->timed(kTimePedestal, [&] {
-                    pedestal_pass(engine->pedestal, stream, m->view(), engine->wing.data,
-                                  engine->core.data, g, count, n_cells);
-                });
-                args.pedestal_cell = engine->pedestal.cell_sum.data;
-                args.pedestal_point = engine->pedestal.point_sum.data;
-            }
-
-            engine->timed(kTimeAccumulate, [&] {
+            engine->timed(kTimeAccumulate, stream, [&] {
                 // One workgroup per tile, padded to a multiple of 8 for the XCD mapping.
                 dim3 grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
                 launch_accumulate(points, grid, stream, args);
             });
 
+            if (with_pedestal)
+            {
+                // The pedestal pre-pass only needs the per-line scalars: it runs on the side
+                // stream next to the accumulate kernel (its serial chain keeps one CU busy).
+                hipStream_t ped_stream = engine->overlap_pedestal ? lane.side : stream;
+                if (engine->overlap_pedestal)
+                {
+                    HIP_TRY(hipStreamWaitEvent(lane.side, lane.prepared, 0));
+                }
+                engine->timed(kTimePedestal, ped_stream, [&] {
+                    pedestal_pass(lane.pedestal, ped_stream, m->view(), lane.wing.data,
+                                  lane.core.data, g, count, n_cells);
+                });
+                if (engine->overlap_pedestal)
+                {
+                    HIP_TRY(hipEventRecord(lane.pedestal_done, lane.side));
+                    HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
+                }
+                dim3 grid((unsigned)((n_long + 255)/256), (unsigned)count);
+                hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, stream, sums,
+                                   sums_stride, target, target_stride,
+                                   lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
+                                   lane.levels.data, g.n, g.n_per_v, n_cells,
+                                   (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0,
+                                   (out_device && add_into) ? 1 : 0);
+                HIP_TRY(hipGetLastError());
+            }
+
             if (!out_device)
             {
                 if (stride == n_long && !(rq.flags & LBL_ACCUMULATE))
                 {
-                    HIP_TRY(hipMemcpyAsync(rq.k + base*stride, engine->staging.data,
+                    HIP_TRY(hipMemcpyAsync(rq.k + base*stride, lane.staging.data,
                                            (size_t)count*n_long*8, hipMemcpyDeviceToHost,
                                            stream));
                     HIP_TRY(hipStreamSynchronize(stream));
@@ -521,7 +650,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 else
                 {
                     std::vector<double> tmp((size_t)count*n_long);
-                    HIP_TRY(hipMemcpyAsync(tmp.data(), engine->staging.data, tmp.size()*8,
+                    HIP_TRY(hipMemcpyAsync(tmp.data(), lane.staging.data, tmp.size()*8,
                                            hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
                     for (int l = 0; l < count; ++l)
@@ -544,7 +673,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         if (rq.evals != nullptr && !(engine->prep == LBL_PREP_HOST))
         {
             unsigned long long total = 0;
-            HIP_TRY(hipMemcpyAsync(&total, engine->evals.data, sizeof(total),
+            HIP_TRY(hipMemcpyAsync(&total, lane.evals.data, sizeof(total),
                                    hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             *rq.evals = (int64_t)total;
@@ -559,7 +688,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
             else if (n_lines > 0)
             {
-                HIP_TRY(hipMemcpyAsync(sorted.data(), engine->derived.data, sorted.size()*8,
+                HIP_TRY(hipMemcpyAsync(sorted.data(), lane.derived.data, sorted.size()*8,
                                        hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
             }
@@ -616,7 +745,8 @@ int lbl_engine_create(int device, lbl_engine ** engine)
         HIP_TRY(hipSetDevice(device));
         std::unique_ptr<lbl_engine> e(new lbl_engine());
         e->device = device;
-        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        for (auto & lane : e->lanes) lane.create();
+        e->stream = e->lanes[0].main;
         *engine = e.release();
     }
     catch (const HipFailure & f)
@@ -630,18 +760,16 @@ int lbl_engine_destroy(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_OK;
     (void)hipSetDevice(engine->device);
-    if (engine->stream != nullptr) (void)hipStreamSynchronize(engine->stream);
+    engine->drain_lanes();
     for (auto & s : engine->spans)
     {
         (void)hipEventDestroy(s.begin);
         (void)hipEventDestroy(s.end);
     }
     for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
-    if (engine->pinned_levels != nullptr) (void)hipHostFree(engine->pinned_levels);
     engine->molecules.clear();
-    hipStream_t stream = engine->stream;
+    for (auto & lane : engine->lanes) lane.destroy();
     delete engine;
-    if (stream != nullptr) (void)hipStreamDestroy(stream);
     return LBL_OK;
 }
 
@@ -754,7 +882,7 @@ int lbl_molecule_free(lbl_engine * engine, int32_t molecule)
         return fail(engine, LBL_BAD_ARGUMENT, "unknown molecule handle.");
     }
     (void)hipSetDevice(engine->device);
-    (void)hipStreamSynchronize(engine->stream);
+    engine->drain_lanes();
     engine->molecules[molecule].reset();
     return LBL_OK;
 }
@@ -790,8 +918,12 @@ int lbl_synchronize(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
     (void)hipSetDevice(engine->device);
-    hipError_t status = hipStreamSynchronize(engine->stream);
-    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    for (auto & lane : engine->lanes)
+    {
+        hipError_t status = hipStreamSynchronize(lane.main);
+        if (status == hipSuccess) status = hipStreamSynchronize(lane.side);
+        if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    }
     return LBL_OK;
 }
 
@@ -811,6 +943,14 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "timing" && (value == 0 || value == 1))
     {
         engine->timing = (int)value;
+    }
+    else if (key == "overlap_pedestal" && (value == 0 || value == 1))
+    {
+        engine->overlap_pedestal = (int)value;
+    }
+    else if (key == "aligned_tiles" && (value == 0 || value == 1))
+    {
+        engine->aligned_tiles = (int)value;
     }
     else if (key == "ablate" && value >= 0 && value <= 3)
     {
@@ -833,7 +973,7 @@ int lbl_timing(lbl_engine * engine, double ms[4], int64_t launches[4], int32_t r
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
-        HIP_TRY(hipStreamSynchronize(engine->stream));
+        engine->drain_lanes();
         engine->drain_spans();
     }
     catch (const HipFailure & f)
@@ -871,7 +1011,7 @@ int lbl_device_free(lbl_engine * engine, void * pointer)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
     (void)hipSetDevice(engine->device);
-    (void)hipStreamSynchronize(engine->stream);
+    engine->drain_lanes();
     hipError_t status = hipFree(pointer);
     if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
     return LBL_OK;

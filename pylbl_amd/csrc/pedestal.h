@@ -20,10 +20,11 @@
 //    piecewise constant between integer wavenumbers, so the accumulate kernel subtracts one
 //    table value per grid point in its epilogue.
 //
-// Kernels: run_scan (find runs in reference row order), run_sums (one wavefront per run:
-// profile values on the run's slots, in parallel over runs), run_chain (one wavefront per
-// level: the only serial part, ~20 flops + one slot-vector update per run, slots in LDS),
-// pedestal_tables (per 1 cm-1 cell: total pedestal covering its interior / its integer point).
+// Kernels: run_count / run_offset / run_compact (find runs in reference row order: a
+// three-pass parallel scan), run_sums (one wavefront per run: profile values on the run's
+// slots, in parallel over runs), run_chain (one wavefront per level: the only serial part,
+// ~20 flops + one slot-vector update per run, everything it touches staged in LDS),
+// pedestal_tables (per 1 cm-1 cell: total pedestal covering its interior / integer point).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -46,8 +47,10 @@ struct RunMeta
     int n_slots;        // integer slots first/npv .. last/npv (+1 if last is not an integer point)
     double vs;          // sum over the run of V_i(first)
     double d;           // sum over the run of V_i(first) - V_i(last)
-    double pedestal;    // filled by run_chain: sum of the run's pedestals
-    double pad;
+    int bin;            // floor(centre) - (v0 - cut_off - 1): identifies the unclipped window
+    int first_slot;     // first/n_per_v
+    int last_slot;      // slot of `last`: last/n_per_v, or n_cells when last is the point n-1
+    int pad;
 };
 
 template <typename T>
@@ -75,11 +78,13 @@ struct RawBuffer
 
 struct PedestalWorkspace
 {
+    RawBuffer<int> block_count;     // [levels][blocks of 1024 rows]
     RawBuffer<int> run_start;       // [levels][n_lines]
     RawBuffer<int> run_count;       // [levels]
     RawBuffer<RunMeta> runs;        // [levels][max_runs]
     RawBuffer<double> slot_sums;    // [levels][max_runs][slot_stride]
-    RawBuffer<double> slots;        // [levels][cells+1]  (only when LDS is too small)
+    RawBuffer<double> slots;        // [levels][cells+1]       (only when LDS is too small)
+    RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]
     RawBuffer<double> cell_sum;     // [levels][cells]
     RawBuffer<double> point_sum;    // [levels][cells]
     std::vector<int> host_counts;
@@ -89,72 +94,103 @@ inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cu
 {
     const long long stride = 2*cut_off + 3;
     const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2));
-    return n_lines*4 + runs*((long long)sizeof(RunMeta) + stride*8) + 3ll*(n_cells + 1)*8;
+    return n_lines*4 + runs*((long long)sizeof(RunMeta) + stride*8) + 4ll*(n_cells + stride)*8;
 }
 
-__device__ __forceinline__ bool window_of_row(const LineWing * __restrict__ wing,
-                                              const int * __restrict__ sorted_of_row,
-                                              long long r, int & first, int & last)
+// A row opens a run when its window is not empty and differs from the previous row's
+// (an empty window in between also ends a run).
+__device__ __forceinline__ int opens_run(const LineWing * __restrict__ wing,
+                                         const int * __restrict__ sorted_of_row,
+                                         long long r, long long n_lines)
 {
+    if (r >= n_lines) return 0;
     const LineWing w = wing[sorted_of_row[r]];
-    first = w.first;
-    last = w.last;
-    return w.first <= w.last;
+    if (w.first > w.last) return 0;
+    if (r == 0) return 1;
+    const LineWing p = wing[sorted_of_row[r - 1]];
+    return (p.first == w.first && p.last == w.last) ? 0 : 1;
 }
 
-// One 1024-thread block per level: marks rows that open a run and compacts their indices.
-__global__ __launch_bounds__(1024) void run_scan_kernel(const LineWing * __restrict__ wing,
-                                                        const int * __restrict__ sorted_of_row,
-                                                        long long n_lines,
-                                                        int * __restrict__ run_start,
-                                                        int * __restrict__ run_count)
+__device__ __forceinline__ int block_inclusive_scan(int value, int * wave_total, int & block_total)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int scan = value;
+    for (int offset = 1; offset < 64; offset <<= 1)
+    {
+        const int up = __shfl_up(scan, offset, 64);
+        if (lane >= offset) scan += up;
+    }
+    if (lane == 63) wave_total[wave] = scan;
+    __syncthreads();
+    int before = 0;
+    block_total = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i)
+    {
+        if (i < wave) before += wave_total[i];
+        block_total += wave_total[i];
+    }
+    __syncthreads();
+    return before + scan;
+}
+
+// Pass 1: runs opened inside every block of 1024 rows.
+__global__ __launch_bounds__(1024) void run_count_kernel(const LineWing * __restrict__ wing,
+                                                         const int * __restrict__ sorted_of_row,
+                                                         long long n_lines, int n_blocks,
+                                                         int * __restrict__ block_count)
+{
+    __shared__ int wave_total[16];
+    const int level = blockIdx.y;
+    const long long r = (long long)blockIdx.x*1024 + threadIdx.x;
+    const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
+    int total;
+    block_inclusive_scan(flag, wave_total, total);
+    if (threadIdx.x == 0) block_count[(long long)level*n_blocks + blockIdx.x] = total;
+}
+
+// Pass 2 (one block per level): exclusive scan of the block counts, in place.
+__global__ __launch_bounds__(1024) void run_offset_kernel(int n_blocks, int * __restrict__ block_count,
+                                                          int * __restrict__ run_count)
 {
     __shared__ int wave_total[16];
     __shared__ int carry;
-    const int level = blockIdx.x;
-    const LineWing * w = wing + (long long)level*n_lines;
-    int * out = run_start + (long long)level*n_lines;
+    int * counts = block_count + (long long)blockIdx.x*n_blocks;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    for (long long base = 0; base < n_lines; base += 1024)
+    for (int base = 0; base < n_blocks; base += 1024)
     {
-        const long long r = base + threadIdx.x;
-        int flag = 0;
-        if (r < n_lines)
-        {
-            int f, l;
-            if (window_of_row(w, sorted_of_row, r, f, l))
-            {
-                flag = 1;
-                if (r > 0)
-                {
-                    int pf, pl;
-                    if (window_of_row(w, sorted_of_row, r - 1, pf, pl) && pf == f && pl == l)
-                    {
-                        flag = 0;
-                    }
-                }
-            }
-        }
-        // Inclusive scan of the flags inside the wavefront, then across the 16 wavefronts.
-        int scan = flag;
-        for (int offset = 1; offset < 64; offset <<= 1)
-        {
-            const int up = __shfl_up(scan, offset, 64);
-            if (lane >= offset) scan += up;
-        }
-        if (lane == 63) wave_total[wave] = scan;
+        const int i = base + threadIdx.x;
+        const int value = i < n_blocks ? counts[i] : 0;
+        int total;
+        const int inclusive = block_inclusive_scan(value, wave_total, total);
+        const int before = carry;
+        if (i < n_blocks) counts[i] = before + inclusive - value;
         __syncthreads();
-        int before = carry;
-        for (int i = 0; i < wave; ++i) before += wave_total[i];
-        if (flag) out[before + scan - 1] = (int)r;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + scan;
+        if (threadIdx.x == 0) carry = before + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) run_count[level] = carry;
+    if (threadIdx.x == 0) run_count[blockIdx.x] = carry;
+}
+
+// Pass 3: rows that open a run, compacted in row order.
+__global__ __launch_bounds__(1024) void run_compact_kernel(const LineWing * __restrict__ wing,
+                                                           const int * __restrict__ sorted_of_row,
+                                                           long long n_lines, int n_blocks,
+                                                           const int * __restrict__ block_offset,
+                                                           int * __restrict__ run_start)
+{
+    __shared__ int wave_total[16];
+    const int level = blockIdx.y;
+    const long long r = (long long)blockIdx.x*1024 + threadIdx.x;
+    const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
+    int total;
+    const int inclusive = block_inclusive_scan(flag, wave_total, total);
+    if (flag)
+    {
+        const int at = block_offset[(long long)level*n_blocks + blockIdx.x] + inclusive - 1;
+        run_start[(long long)level*n_lines + at] = (int)r;
+    }
 }
 
 __device__ __forceinline__ int slot_point(int slot, int n_cells, int n_per_v, int n)
@@ -163,7 +199,7 @@ __device__ __forceinline__ int slot_point(int slot, int n_cells, int n_per_v, in
 }
 
 // One wavefront per run (grid-stride over runs): evaluates every row of the run on the
-// run's slots with the same profile code the accumulate kernel uses.
+// run's slots (lane = slot) with the same profile code the accumulate kernel uses.
 __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restrict__ wing,
                                                       const LineCore * __restrict__ core,
                                                       const int * __restrict__ sorted_of_row,
@@ -199,6 +235,8 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
             const int point = slot_point(active ? slot : first_slot, n_cells, g.n_per_v, g.n);
             const double step = (double)point*g.dv;        // absorption.c:39
             const double v = (double)g.v0 + step;
+            const bool holds_first = (q0 == 0);
+            const bool holds_last = (q0 + 64 >= n_slots);
             double total = 0.;
             for (int r = row_begin; r < row_end; ++r)
             {
@@ -220,27 +258,15 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                     value = k.amp*wells_profile(d*k.repwid, k.y);
                 }
                 total += value;
-                if (q0 == 0)
+                if (holds_first)
                 {
                     const double at_first = __shfl(value, 0, 64);
-                    const int last_lane = (n_slots - 1) & 63;
-                    // V_i(last) lives in the final 64-slot group; fetched there.
-                    if (n_slots <= 64)
-                    {
-                        const double at_last = __shfl(value, last_lane, 64);
-                        vs += at_first;
-                        dd += at_first - at_last;
-                    }
-                    else
-                    {
-                        vs += at_first;
-                        dd += at_first;
-                    }
+                    vs += at_first;
+                    dd += at_first;
                 }
-                else if (q0 + 64 >= n_slots)
+                if (holds_last)
                 {
-                    const double at_last = __shfl(value, (n_slots - 1 - q0), 64);
-                    dd -= at_last;
+                    dd -= __shfl(value, n_slots - 1 - q0, 64);
                 }
             }
             if (active) sums[q] = total;
@@ -254,91 +280,219 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
             meta.n_slots = n_slots;
             meta.vs = vs;
             meta.d = dd;
-            meta.pedestal = 0.;
-            meta.pad = 0.;
+            meta.bin = (int)floor(head.centre) - (g.v0 - g.cut_off - 1);
+            meta.first_slot = first_slot;
+            meta.last_slot = extra ? n_cells : last_int;
+            meta.pad = 0;
             runs[(long long)level*max_runs + run] = meta;
         }
     }
 }
 
-// One wavefront per level: the serial recurrence over runs.  `a` holds the accumulated
-// spectrum on the slots (LDS when it fits, HBM otherwise).
+__device__ __forceinline__ double read_lane(double value, int lane)
+{
+    const long long bits = __double_as_longlong(value);
+    const int lo = __builtin_amdgcn_readlane((int)bits, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at a time
+
+// One wavefront per level: the serial recurrence over runs.  Slots (the accumulated
+// spectrum on integer wavenumbers) and the per-window pedestal totals live in LDS; the
+// inputs of the next kChainChunk runs are staged cooperatively so that no global-memory
+// latency sits on the serial chain.
 template <bool USE_LDS>
 __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ run_count,
                                                        int max_runs, int slot_stride,
-                                                       GridSpec g, int n_cells,
-                                                       RunMeta * __restrict__ runs,
+                                                       GridSpec g, int n_cells, int n_bins,
+                                                       const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
-                                                       double * __restrict__ global_slots)
+                                                       double * __restrict__ global_slots,
+                                                       double * __restrict__ bin_sum)
 {
-    extern __shared__ double lds_slots[];
+    extern __shared__ double lds[];
     const int level = blockIdx.x;
     const int lane = threadIdx.x;
-    double * a = USE_LDS ? lds_slots : global_slots + (long long)level*(n_cells + 1);
+    // LDS carve: [2 x staged slot sums][slots][bin sums]; without LDS room the last two are in HBM.
+    double * staged = lds;
+    double * a = USE_LDS ? lds + 2*kChainChunk*slot_stride
+                         : global_slots + (long long)level*(n_cells + 1);
+    double * bins = USE_LDS ? a + (n_cells + 1) : bin_sum + (long long)level*n_bins;
     for (int s = lane; s <= n_cells; s += 64) a[s] = 0.;
+    for (int s = lane; s < n_bins; s += 64) bins[s] = 0.;
     __syncthreads();
     const int count = run_count[level];
-    RunMeta * meta = runs + (long long)level*max_runs;
+    const RunMeta * meta = runs + (long long)level*max_runs;
     const double * sums = slot_sums + (long long)level*max_runs*slot_stride;
-    for (int run = 0; run < count; ++run)
-    {
-        const RunMeta m = meta[run];
-        const int first_slot = m.first/g.n_per_v;
-        const int last_int = m.last/g.n_per_v;
-        const bool extra = (last_int*g.n_per_v != m.last);
-        const int last_slot = extra ? n_cells : last_int;
-        const double a_s = a[first_slot];
-        const double a_e = a[last_slot];
-        const double delta_n = (a_s - a_e) + m.d;
-        const double s_new = delta_n > 0. ? delta_n : 0.;
-        const double e_new = delta_n < 0. ? -delta_n : 0.;
-        const double pedestal = (a_s + m.vs) - s_new;
-        __syncthreads();   // single wavefront: orders the LDS reads above before the writes
-        for (int q = lane; q < m.n_slots; q += 64)
+    // Inputs of chunk c+1 are fetched into registers while chunk c is being chained, and
+    // parked in the other half of the LDS staging area afterwards: no global-memory latency
+    // on the serial path.  (kStageLoads*64 doubles cover a chunk for cut_off <= 30.)
+    constexpr int kStageLoads = kChainChunk;
+    const bool prefetch = kChainChunk*slot_stride <= kStageLoads*64;
+    double ahead[kStageLoads];
+    RunMeta mine_next;
+    auto fetch = [&](int base) {
+        const int chunk = min(kChainChunk, count - base);
+        mine_next = meta[base + min(lane, max(chunk - 1, 0))];
+#pragma unroll
+        for (int u = 0; u < kStageLoads; ++u)
         {
-            const int slot = (extra && q == m.n_slots - 1) ? n_cells : first_slot + q;
-            double value;
-            if (q == 0) value = s_new;
-            else if (q == m.n_slots - 1) value = e_new;
-            else value = a[slot] + (sums[(long long)run*slot_stride + q] - pedestal);
-            if (m.n_slots == 1) value = 0.;
-            a[slot] = value;
+            const int i = u*64 + lane;
+            ahead[u] = i < chunk*slot_stride ? sums[(long long)base*slot_stride + i] : 0.;
+        }
+    };
+    auto park = [&](double * where, int chunk) {
+#pragma unroll
+        for (int u = 0; u < kStageLoads; ++u)
+        {
+            const int i = u*64 + lane;
+            if (i < chunk*slot_stride) where[i] = ahead[u];
+        }
+    };
+    double * stage_a = lds;
+    double * stage_b = lds + kChainChunk*slot_stride;
+    if (prefetch && count > 0)
+    {
+        fetch(0);
+        park(stage_a, min(kChainChunk, count));
+    }
+    for (int base = 0; base < count; base += kChainChunk)
+    {
+        const int chunk = min(kChainChunk, count - base);
+        RunMeta mine;
+        if (prefetch)
+        {
+            mine = mine_next;
+            staged = ((base/kChainChunk) & 1) ? stage_b : stage_a;
+            if (base + kChainChunk < count) fetch(base + kChainChunk);
+        }
+        else
+        {
+            mine = meta[base + min(lane, chunk - 1)];
+            for (int i = lane; i < chunk*slot_stride; i += 64)
+            {
+                staged[i] = sums[(long long)base*slot_stride + i];
+            }
         }
         __syncthreads();
-        if (lane == 0) meta[run].pedestal = pedestal;
+        for (int r = 0; r < chunk; ++r)
+        {
+            // Run r's scalars are wave-uniform: v_readlane, no LDS traffic.
+            const int n_slots = __builtin_amdgcn_readlane(mine.n_slots, r);
+            const int bin = __builtin_amdgcn_readlane(mine.bin, r);
+            const int first_slot = __builtin_amdgcn_readlane(mine.first_slot, r);
+            const int last_slot = __builtin_amdgcn_readlane(mine.last_slot, r);
+            const double vs = read_lane(mine.vs, r);
+            const double dd = read_lane(mine.d, r);
+            const bool bin_ok = bin >= 0 && bin < n_bins;
+            // Everything the step reads is requested up front (one LDS round trip); the
+            // interior slots do not depend on the end slots.
+            const bool interior = lane > 0 && lane < n_slots - 1 && lane < 64;
+            const double a_s = a[first_slot];
+            const double a_e = a[last_slot];
+            const double bin_old = bins[bin_ok ? bin : 0];
+            const double mid = interior ? a[first_slot + lane] : 0.;
+            const double add = interior ? staged[r*slot_stride + lane] : 0.;
+            const double delta_n = (a_s - a_e) + dd;
+            const double s_new = delta_n > 0. ? delta_n : 0.;
+            const double e_new = delta_n < 0. ? -delta_n : 0.;
+            const double pedestal = n_slots == 1 ? a_s + vs : (a_s + vs) - s_new;
+            // One wavefront owns this memory: its LDS accesses execute in program order, so
+            // only the compiler has to be kept from reordering them.
+            __builtin_amdgcn_wave_barrier();
+            if (n_slots <= 64)
+            {
+                double value = mid + (add - pedestal);
+                if (lane == 0) value = s_new;
+                if (lane == n_slots - 1) value = e_new;
+                if (n_slots == 1) value = 0.;
+                const int slot = (lane == n_slots - 1) ? last_slot : first_slot + lane;
+                if (lane < n_slots) a[slot] = value;
+            }
+            else
+            {
+                // Windows wider than 64 slots (cut_off > 30).
+                for (int q = lane; q < n_slots; q += 64)
+                {
+                    const int slot = (q == n_slots - 1) ? last_slot : first_slot + q;
+                    double value;
+                    if (q == 0) value = s_new;
+                    else if (q == n_slots - 1) value = e_new;
+                    else value = a[slot] + (staged[r*slot_stride + q] - pedestal);
+                    a[slot] = value;
+                }
+            }
+            if (lane == 0 && bin_ok) bins[bin] = bin_old + pedestal;
+            if (USE_LDS)
+            {
+                __builtin_amdgcn_wave_barrier();
+            }
+            else
+            {
+                __syncthreads();    // HBM fallback: wait for the stores before the next reads
+            }
+        }
+        if (prefetch && base + kChainChunk < count)
+        {
+            park(((base/kChainChunk) & 1) ? stage_a : stage_b,
+                 min(kChainChunk, count - base - kChainChunk));
+        }
+        __syncthreads();
+    }
+    if (USE_LDS)
+    {
+        for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = bins[s];
     }
 }
 
-// One thread per 1 cm-1 cell: total pedestal of the runs whose window holds the cell's
-// interior points / its integer point.  Runs are read in order (wave-uniform loads), so the
-// sums are reproducible.
-__global__ __launch_bounds__(256) void pedestal_tables_kernel(const int * __restrict__ run_count,
-                                                              int max_runs, GridSpec g,
-                                                              int n_cells,
-                                                              const RunMeta * __restrict__ runs,
+// One thread per 1 cm-1 cell: the interior points of cell c lie in the windows of bins
+// b = c+v0-cut .. c+v0+cut, its integer point also in bin c+v0-cut-1 (the window that closes
+// there).  Sums of non-negative totals in a fixed order: reproducible, and exactly zero where
+// no line reaches.
+__global__ __launch_bounds__(256) void pedestal_tables_kernel(GridSpec g, int n_cells, int n_bins,
+                                                              const double * __restrict__ bin_sum,
                                                               double * __restrict__ cell_sum,
                                                               double * __restrict__ point_sum)
 {
     const int level = blockIdx.y;
     const int cell = blockIdx.x*blockDim.x + threadIdx.x;
-    const int count = run_count[level];
-    const RunMeta * meta = runs + (long long)level*max_runs;
-    const long long lo = (long long)cell*g.n_per_v;           // the integer point
-    const long long in_lo = lo + 1;                            // interior of the cell
-    const long long in_hi = lo + g.n_per_v - 1;
-    double interior = 0., point = 0.;
-    for (int run = 0; run < count; ++run)
+    if (cell >= n_cells) return;
+    const double * bins = bin_sum + (long long)level*n_bins;
+    double interior = 0.;
+    for (int k = 1; k <= 2*g.cut_off + 1; ++k)
     {
-        const int first = meta[run].first, last = meta[run].last;
-        const double p = meta[run].pedestal;
-        if (first <= lo && lo <= last) point += p;
-        if (first <= in_lo && in_hi <= last) interior += p;
+        interior += bins[cell + k];
     }
-    if (cell < n_cells)
-    {
-        cell_sum[(long long)level*n_cells + cell] = interior;
-        point_sum[(long long)level*n_cells + cell] = point;
-    }
+    cell_sum[(long long)level*n_cells + cell] = interior;
+    point_sum[(long long)level*n_cells + cell] = interior + bins[cell];
+}
+
+// k = (sums - pedestal total of the windows holding the point) [* number density] [+ k].
+// Windows start and end on integer wavenumbers, so the total is constant inside a 1 cm-1
+// cell and has one extra bin of lines on the integer point that closes a window.
+__global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __restrict__ sums,
+                                                             long long sums_stride,
+                                                             double * __restrict__ out,
+                                                             long long out_stride,
+                                                             const double * __restrict__ cell_sum,
+                                                             const double * __restrict__ point_sum,
+                                                             const LevelScalars * __restrict__ levels,
+                                                             int n, int n_per_v, int n_cells,
+                                                             int scale_density, int accumulate)
+{
+    const int level = blockIdx.y;
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cell = i/n_per_v;
+    const bool on_integer = (cell*n_per_v == i);
+    const double * table = on_integer ? point_sum : cell_sum;
+    double value = sums[(long long)level*sums_stride + i] - table[(long long)level*n_cells + cell];
+    if (scale_density) value *= levels[level].density;
+    double * k = out + (long long)level*out_stride;
+    if (accumulate) value += k[i];
+    k[i] = value;
 }
 
 // Runs the whole pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are
@@ -355,13 +509,22 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
     };
     const long long n_lines = t.n_lines;
     const int slot_stride = 2*g.cut_off + 3;
+    const int n_bins = n_cells + 2*g.cut_off + 3;
+    const int n_blocks = (int)((n_lines + 1023)/1024);
+    ws.block_count.reserve((size_t)count*n_blocks);
     ws.run_start.reserve((size_t)(count*n_lines));
     ws.run_count.reserve((size_t)count);
+    ws.bin_sum.reserve((size_t)count*n_bins);
     ws.cell_sum.reserve((size_t)count*n_cells);
     ws.point_sum.reserve((size_t)count*n_cells);
-    hipLaunchKernelGGL(run_scan_kernel, dim3(count), dim3(1024), 0, stream, wing,
-                       t.sorted_of_row, n_lines, ws.run_start.data, ws.run_count.data);
-    check(hipGetLastError(), "run_scan_kernel");
+    hipLaunchKernelGGL(run_count_kernel, dim3(n_blocks, count), dim3(1024), 0, stream, wing,
+                       t.sorted_of_row, n_lines, n_blocks, ws.block_count.data);
+    hipLaunchKernelGGL(run_offset_kernel, dim3(count), dim3(1024), 0, stream, n_blocks,
+                       ws.block_count.data, ws.run_count.data);
+    hipLaunchKernelGGL(run_compact_kernel, dim3(n_blocks, count), dim3(1024), 0, stream, wing,
+                       t.sorted_of_row, n_lines, n_blocks, ws.block_count.data,
+                       ws.run_start.data);
+    check(hipGetLastError(), "run scan kernels");
     ws.host_counts.resize((size_t)count);
     check(hipMemcpyAsync(ws.host_counts.data(), ws.run_count.data, count*sizeof(int),
                          hipMemcpyDeviceToHost, stream), "run count copy");
@@ -375,8 +538,9 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
                        ws.run_start.data, ws.run_count.data, max_runs, slot_stride,
                        ws.runs.data, ws.slot_sums.data);
     check(hipGetLastError(), "run_sums_kernel");
-    const size_t lds_bytes = (size_t)(n_cells + 1)*sizeof(double);
-    if (lds_bytes <= 160*1024 - 256)
+    const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
+    const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
+    if (lds_bytes <= 160*1024 - 512)
     {
         if (lds_bytes > 64*1024)
         {
@@ -385,20 +549,20 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
                                       (int)lds_bytes), "LDS opt-in");
         }
         hipLaunchKernelGGL(run_chain_kernel<true>, dim3(count), dim3(64), lds_bytes, stream,
-                           ws.run_count.data, max_runs, slot_stride, g, n_cells, ws.runs.data,
-                           ws.slot_sums.data, (double *)nullptr);
+                           ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
+                           ws.runs.data, ws.slot_sums.data, (double *)nullptr, ws.bin_sum.data);
     }
     else
     {
         ws.slots.reserve((size_t)count*(n_cells + 1));
-        hipLaunchKernelGGL(run_chain_kernel<false>, dim3(count), dim3(64), 0, stream,
-                           ws.run_count.data, max_runs, slot_stride, g, n_cells, ws.runs.data,
-                           ws.slot_sums.data, ws.slots.data);
+        hipLaunchKernelGGL(run_chain_kernel<false>, dim3(count), dim3(64), staged_bytes, stream,
+                           ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
+                           ws.runs.data, ws.slot_sums.data, ws.slots.data, ws.bin_sum.data);
     }
     check(hipGetLastError(), "run_chain_kernel");
     hipLaunchKernelGGL(pedestal_tables_kernel, dim3((n_cells + 255)/256, count), dim3(256), 0,
-                       stream, ws.run_count.data, max_runs, g, n_cells, ws.runs.data,
-                       ws.cell_sum.data, ws.point_sum.data);
+                       stream, g, n_cells, n_bins, ws.bin_sum.data, ws.cell_sum.data,
+                       ws.point_sum.data);
     check(hipGetLastError(), "pedestal_tables_kernel");
 }
 

@@ -115,19 +115,18 @@ __device__ inline int first_above(const double * __restrict__ nu, int n, double 
 //   tile may touch |x|<xlim0    |nu - tile| <= core_reach*nu (+ shift)
 __global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict__ nu, int n_lines,
                                                        const LevelScalars * __restrict__ levels,
-                                                       const GridSpec g, int tile_points,
-                                                       int n_tiles,
+                                                       const GridSpec g, const Tiling tiling,
                                                        TileSchedule * __restrict__ schedule)
 {
     const int tile = blockIdx.x*blockDim.x + threadIdx.x;
     const int level = blockIdx.y;
+    const int n_tiles = tiling.n_tiles;
     if (tile >= n_tiles)
     {
         return;
     }
-    const long long i0 = (long long)tile*tile_points;
-    long long i1 = i0 + tile_points - 1;
-    if (i1 > g.n - 1) i1 = g.n - 1;
+    long long i0, i1;
+    tile_bounds(tiling, tile, g.n_per_v, g.n, i0, i1);
     const double smax = levels[level].shift_max;
     const long long npv = g.n_per_v;
     const double any_lo = (double)((i0 + npv - 1)/npv + g.v0 - g.cut_off - 1);

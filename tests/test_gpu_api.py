@@ -140,6 +140,35 @@ def test_device_output_scale_and_accumulate(oracle):
     e.close()
 
 
+def test_asynchronous_pedestal_calls_share_the_gpu(oracle):
+    """Asynchronous calls with a pedestal rotate over the engine's lanes (own streams and
+    workspaces); results must equal the blocking calls bit for bit."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    tables = [synthetic.line_table(f, 1., 120., num_lines=400 + 100*i, seed=60 + i,
+                                   tips_range=(150, 400))
+              for i, f in enumerate(("H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2", "H2O",
+                                     "CO2"))]
+    handles = [e.load(t) for t in tables]
+    atmos = synthetic.fixture_atmosphere()
+    v0, vn, npv = 1, 91, 40
+    outs = [DeviceSpectra(e, 4, (vn - v0)*npv) for _ in tables]
+    for _ in range(2):      # second round reuses every lane's workspace
+        for h, t, out in zip(handles, tables, outs):
+            e.compute(h, atmos.t, atmos.p, atmos.vmr[t.formula], v0, vn, npv,
+                      remove_pedestal=True, out=out, asynchronous=True)
+    e.synchronize()
+    for h, t, out in zip(handles, tables, outs):
+        blocking = e.compute(h, atmos.t, atmos.p, atmos.vmr[t.formula], v0, vn, npv,
+                             remove_pedestal=True)
+        assert np.array_equal(out.to_host(), blocking)
+        k_ref, _ = oracle.absorption_port(t, atmos.t[3], atmos.p[3], atmos.vmr[t.formula][3],
+                                          v0, vn, npv, remove_pedestal=True)
+        check(blocking[3], k_ref, npv, True, t.formula)
+        out.free()
+    e.close()
+
+
 def test_error_paths():
     from pylbl_amd.engine import Engine
     from pylbl_amd.errors import EngineError

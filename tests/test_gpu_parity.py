@@ -110,8 +110,9 @@ def test_eval_count_matches_oracle(engine, oracle):
     engine.free(molecule)
 
 
+@pytest.mark.parametrize("aligned", [1, 0])
 @pytest.mark.parametrize("remove_pedestal", [False, True])
-def test_seeded_against_oracle_fine_grid(engine, oracle, remove_pedestal):
+def test_seeded_against_oracle_fine_grid(engine, oracle, remove_pedestal, aligned):
     """A 0.001 cm-1 grid (the benchmark resolution) at sizes the oracle finishes in seconds,
     all four fixture levels: exercises full-cover fast loops, core rows and clipping."""
     from pylbl_amd import synthetic
@@ -119,8 +120,10 @@ def test_seeded_against_oracle_fine_grid(engine, oracle, remove_pedestal):
     atmos = synthetic.fixture_atmosphere()
     v0, vn, npv = 600, 640, 1000
     molecule = engine.load(table)
+    engine.set_option("aligned_tiles", aligned)     # cell-aligned tiles vs plain 64*P tiles
     k = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
                        remove_pedestal=remove_pedestal)
+    engine.set_option("aligned_tiles", 0)
     case = golden_io.Case("seeded", 0, 0, 0, 0, v0, vn, npv, 25, remove_pedestal, None, 0)
     for i in range(atmos.t.size):
         k_ref, _ = oracle.absorption_port(table, atmos.t[i], atmos.p[i], atmos.vmr["CO2"][i],
