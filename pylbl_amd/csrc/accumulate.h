@@ -72,9 +72,6 @@ struct AccumulateArgs
     const LineCore * core;          // [levels][n_lines]
     const TileSchedule * schedule;  // [levels][n_tiles]
     const LevelScalars * levels;    // [levels]
-    const double * pedestal_cell;   // [levels][cells] or nullptr
-    const double * pedestal_point;  // [levels][cells] or nullptr
-    int n_cells;                    // vn - v0
     double * k;                     // [levels][level_stride]
     long long level_stride;
     long long n_lines;
@@ -239,7 +236,7 @@ __device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, in
 // One 256-thread workgroup per tile.  Its four wavefronts own the SAME 64*P grid points and
 // split the tile's lines four ways (every cut-point range is quartered), so a tile is four
 // independent work items for the dispatcher instead of one; the four partial sums meet in
-// LDS and each wavefront finishes P/4 of the rows (pedestal, scaling, the one store of k).
+// LDS and each wavefront finishes P/4 of the rows (scaling, the one store of k).
 template <int P>
 __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
 {
@@ -320,17 +317,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
             // Fixed order of the four partial sums: results do not depend on scheduling.
             double value = (partial[0][p][lane] + partial[1][p][lane]) +
                            (partial[2][p][lane] + partial[3][p][lane]);
-            if (a.pedestal_cell != nullptr)
-            {
-                // Sum of the pedestals of every line whose window holds point i
-                // (spectra.c:66-78 factorised; see pedestal.h).  Windows start and end on
-                // integer wavenumbers, so the sum is constant inside a 1 cm-1 cell and has
-                // one extra bin of lines on the integer point that closes a window.
-                const int cell = i/a.n_per_v;
-                const bool on_integer = (cell*a.n_per_v == i);
-                const double * table = on_integer ? a.pedestal_point : a.pedestal_cell;
-                value -= table[(long long)level*a.n_cells + cell];
-            }
             value *= scale;
             if (a.accumulate)
             {

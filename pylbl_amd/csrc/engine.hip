@@ -587,9 +587,6 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.core = lane.core.data;
             args.schedule = lane.schedule.data;
             args.levels = lane.levels.data;
-            args.pedestal_cell = nullptr;
-            args.pedestal_point = nullptr;
-            args.n_cells = n_cells;
             args.level_stride = sums_stride;
             args.k = sums;
             args.n_lines = n_lines;
