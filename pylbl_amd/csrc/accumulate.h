@@ -66,12 +66,27 @@ struct alignas(32) TileSchedule
     int pad0, pad1;
 };
 
+// One unit of work for a workgroup: part `part` of `parts` of tile `tile`'s lines.  Dense
+// spectral bands give some tiles many times the average number of lines; the host splits
+// those into several items (and orders items heaviest first) so that no single workgroup
+// holds up the kernel.  Items of a split tile store plain partial sums into
+// partial[slot + part], which combine_kernel adds up in a fixed order.
+struct alignas(16) WorkItem
+{
+    int tile;
+    int part, parts;
+    int slot;           // first partial slot of the tile (parts > 1), else -1
+};
+
 struct AccumulateArgs
 {
     const LineWing * wing;          // [levels][n_lines]
     const LineCore * core;          // [levels][n_lines]
     const TileSchedule * schedule;  // [levels][n_tiles]
     const LevelScalars * levels;    // [levels]
+    const WorkItem * items;         // [n_items]
+    double * partial;               // [levels][partial_slots][64*P] sums of split tiles
+    long long partial_slots;
     double * k;                     // [levels][level_stride]
     long long level_stride;
     long long n_lines;
@@ -233,10 +248,11 @@ __device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, in
     end = (part + 1 == parts) ? j1 : j0 + (int)(((long long)units*(part + 1))/parts)*unit;
 }
 
-// One 256-thread workgroup per tile.  Its four wavefronts own the SAME 64*P grid points and
-// split the tile's lines four ways (every cut-point range is quartered), so a tile is four
-// independent work items for the dispatcher instead of one; the four partial sums meet in
-// LDS and each wavefront finishes P/4 of the rows (scaling, the one store of k).
+// One 256-thread workgroup per work item.  Its four wavefronts own the SAME 64*P grid points
+// and split the item's lines four ways (every cut-point range is first cut into the item's
+// share, then quartered), so an item is four independent wavefronts for the dispatcher; the
+// four partial sums meet in LDS and each wavefront finishes P/4 of the rows (scaling, the
+// one store of k -- or of the item's partial sums when the tile was split).
 template <int P>
 __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
 {
@@ -244,15 +260,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int level = blockIdx.y;
-    // Workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous eighth
-    // of the spectrum so that neighbouring tiles (which share most of their lines) meet in
-    // the same L2.  Placement only changes speed.
-    const int per_xcd = (a.n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
-    if (tile >= a.n_tiles)
-    {
-        return;
-    }
+    const WorkItem item = a.items[blockIdx.x];
+    const int tile = item.tile;
     long long first_point, last_point;
     tile_bounds(a.tiling, tile, a.n_per_v, a.n, first_point, last_point);
     const int i0 = (int)first_point, i1 = (int)last_point;
@@ -271,17 +280,19 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         acc[p] = 0.;
     }
 
-    // This wavefront's quarter of each of the five cut-point ranges.
+    // This wavefront's share of each of the five cut-point ranges: the item's part of the
+    // range, quartered.
+    const int piece = item.part*4 + wave, pieces = item.parts*4;
     GeneralList g;
     int fa0, fa1, fb0, fb1, e;
-    share_of(sc.lo, sc.a1, wave, 4, 1, g.begin[0], e);
+    share_of(sc.lo, sc.a1, piece, pieces, 1, g.begin[0], e);
     g.count[0] = e - g.begin[0];
-    share_of(sc.c1, sc.c2, wave, 4, 1, g.begin[1], e);
+    share_of(sc.c1, sc.c2, piece, pieces, 1, g.begin[1], e);
     g.count[1] = e - g.begin[1];
-    share_of(sc.a2, sc.hi, wave, 4, 1, g.begin[2], e);
+    share_of(sc.a2, sc.hi, piece, pieces, 1, g.begin[2], e);
     g.count[2] = e - g.begin[2];
-    share_of(sc.a1, sc.c1, wave, 4, 4, fa0, fa1);
-    share_of(sc.c2, sc.a2, wave, 4, 4, fb0, fb1);
+    share_of(sc.a1, sc.c1, piece, pieces, 4, fa0, fa1);
+    share_of(sc.c2, sc.a2, piece, pieces, 4, fb0, fb1);
     // Left-over lines of the far-wing ranges (fewer than four each) take the general path.
     g.begin[3] = fa0 + ((fa1 - fa0) & ~3);
     g.count[3] = (fa1 - fa0) & 3;
@@ -303,6 +314,20 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     }
     __syncthreads();
 
+    if (item.parts > 1)
+    {
+        // A split tile: plain sums to this item's slot; combine_kernel finishes.
+        double * __restrict__ slot = a.partial +
+            ((long long)level*a.partial_slots + item.slot + item.part)*(64*P);
+        for (int p = wave; p < P; p += 4)
+        {
+            // Fixed order of the four partial sums: results do not depend on scheduling.
+            slot[p*64 + lane] = (partial[0][p][lane] + partial[1][p][lane]) +
+                                (partial[2][p][lane] + partial[3][p][lane]);
+        }
+        return;
+    }
+
     double scale = 1.;
     if (a.scale_density)
     {
@@ -314,7 +339,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         const int i = i0 + p*64 + lane;
         if (i <= i1)
         {
-            // Fixed order of the four partial sums: results do not depend on scheduling.
             double value = (partial[0][p][lane] + partial[1][p][lane]) +
                            (partial[2][p][lane] + partial[3][p][lane]);
             value *= scale;
@@ -325,6 +349,41 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
             out[i] = value;
         }
     }
+}
+
+// Adds up the partial sums of the split tiles, part 0 first (fixed order), and writes k.
+// One 64-thread group per (64-point row of a split tile, level).
+struct SplitTile
+{
+    int tile, parts, slot, pad;
+};
+
+__global__ __launch_bounds__(256) void combine_kernel(const AccumulateArgs a,
+                                                      const SplitTile * __restrict__ tiles,
+                                                      int n_split, int points)
+{
+    const int level = blockIdx.y;
+    const int rows = points >> 6;
+    const int unit = blockIdx.x*4 + (threadIdx.x >> 6);     // (split tile, row)
+    const int lane = threadIdx.x & 63;
+    if (unit >= n_split*rows) return;
+    const SplitTile t = tiles[unit/rows];
+    const int p = unit - (unit/rows)*rows;
+    long long first_point, last_point;
+    tile_bounds(a.tiling, t.tile, a.n_per_v, a.n, first_point, last_point);
+    const long long i = first_point + p*64 + lane;
+    if (i > last_point) return;
+    const double * slot = a.partial + ((long long)level*a.partial_slots + t.slot)*points +
+                          p*64 + lane;
+    double value = 0.;
+    for (int part = 0; part < t.parts; ++part)
+    {
+        value += slot[(long long)part*points];
+    }
+    if (a.scale_density) value *= a.levels[level].density;
+    double * out = a.k + (long long)level*a.level_stride;
+    if (a.accumulate) value += out[i];
+    out[i] = value;
 }
 
 }  // namespace lbl

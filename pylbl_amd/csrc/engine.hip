@@ -99,6 +99,17 @@ struct Molecule
     DeviceBuffer<double> d_column[7];
     DeviceBuffer<int> d_iso_slot, d_row, d_sorted_of_row;
 
+    // Work-item plans, one per (grid, cut_off, tiling) this molecule has been computed on.
+    struct Plan
+    {
+        int v0, vn, n_per_v, cut_off, points, aligned;
+        int n_items = 0, n_split = 0;
+        long long partial_slots = 0;
+        DeviceBuffer<WorkItem> items;
+        DeviceBuffer<SplitTile> split;
+    };
+    std::vector<std::unique_ptr<Plan>> plans;
+
     LineTableView view() const
     {
         LineTableView v;
@@ -128,6 +139,7 @@ struct Lane
     DeviceBuffer<LevelScalars> levels;
     DeviceBuffer<double> staging;   // spectra on their way to host memory
     DeviceBuffer<double> raw;       // un-pedestalled sums when the output must be added to
+    DeviceBuffer<double> partial;   // partial sums of split tiles
     DeviceBuffer<double> derived;
     DeviceBuffer<unsigned long long> evals;
     PedestalWorkspace pedestal;
@@ -369,6 +381,78 @@ int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & ti
     return p;
 }
 
+// Splits the tiles into work items of bounded size and orders them heaviest first.  Line
+// counts per tile come from the sorted wavenumbers alone (pressure shifts move them by a line
+// or two, which does not matter for balance); the exact per-level cut points are still the
+// schedule kernel's.
+Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
+                          const Tiling & tiling, int points, hipStream_t stream)
+{
+    for (auto & p : m.plans)
+    {
+        if (p->v0 == g.v0 && p->vn == g.vn && p->n_per_v == g.n_per_v &&
+            p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned)
+        {
+            return *p;
+        }
+    }
+    std::unique_ptr<Molecule::Plan> plan(new Molecule::Plan());
+    plan->v0 = g.v0; plan->vn = g.vn; plan->n_per_v = g.n_per_v; plan->cut_off = g.cut_off;
+    plan->points = points; plan->aligned = tiling.aligned;
+    const int n_tiles = tiling.n_tiles;
+    const std::vector<double> & nu = m.column[0];
+    std::vector<long long> weight((size_t)n_tiles);
+    long long total = 0;
+    for (int t = 0; t < n_tiles; ++t)
+    {
+        long long i0, i1;
+        tile_bounds(tiling, t, g.n_per_v, g.n, i0, i1);
+        const double lo = (double)((i0 + g.n_per_v - 1)/g.n_per_v + g.v0 - g.cut_off - 1) - 0.05;
+        const double hi = (double)(i1/g.n_per_v + g.v0 + g.cut_off) + 1.05;
+        weight[t] = std::lower_bound(nu.begin(), nu.end(), hi) -
+                    std::lower_bound(nu.begin(), nu.end(), lo);
+        total += weight[t];
+    }
+    // Aim for ~16 items per workgroup slot of the chip (256 CUs x ~5 resident workgroups),
+    // but never items smaller than 512 lines.
+    const long long target = std::max<long long>(512, total/(16*1280) + 1);
+    std::vector<WorkItem> items;
+    std::vector<SplitTile> split;
+    std::vector<long long> item_weight;
+    long long slots = 0;
+    for (int t = 0; t < n_tiles; ++t)
+    {
+        int parts = (int)std::min<long long>(64, (weight[t] + target - 1)/target);
+        if (parts < 1) parts = 1;
+        const int slot = parts > 1 ? (int)slots : -1;
+        if (parts > 1)
+        {
+            split.push_back(SplitTile{t, parts, slot, 0});
+            slots += parts;
+        }
+        for (int k = 0; k < parts; ++k)
+        {
+            items.push_back(WorkItem{t, k, parts, slot});
+            item_weight.push_back(weight[t]/parts);
+        }
+    }
+    std::vector<int> order(items.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return item_weight[a] > item_weight[b]; });
+    std::vector<WorkItem> sorted(items.size());
+    for (size_t i = 0; i < items.size(); ++i) sorted[i] = items[order[i]];
+    plan->n_items = (int)sorted.size();
+    plan->n_split = (int)split.size();
+    plan->partial_slots = slots;
+    plan->items.upload(sorted.data(), sorted.size(), stream);
+    plan->split.upload(split.data(), split.size(), stream);
+    HIP_TRY(hipStreamSynchronize(stream));      // the host vectors go out of scope
+    (void)engine;
+    m.plans.push_back(std::move(plan));
+    return *m.plans.back();
+}
+
 void launch_accumulate(int points, dim3 grid, hipStream_t stream, const AccumulateArgs & args)
 {
     switch (points)
@@ -453,8 +537,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         }
         hipStream_t stream = lane.main;
 
+        Molecule::Plan & plan = plan_for(engine, *m, g, tiling, points, stream);
+
         // Levels per pass, bounded by the workspace budget.
-        const long long per_level = n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
+        const long long per_level = plan.partial_slots*64*points*8 + n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
                                     (long long)n_tiles*sizeof(TileSchedule) +
                                     (out_device ? 0 : n_long*8) +
                                     (rq.remove_pedestal ? pedestal_bytes_per_level(n_lines, n_cells, rq.cut_off) : 0);
@@ -477,6 +563,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         lane.schedule.reserve((size_t)(chunk*n_tiles));
         if (want_k && !out_device) lane.staging.reserve((size_t)(chunk*n_long));
         if (with_pedestal && out_device && add_into) lane.raw.reserve((size_t)(chunk*n_long));
+        if (want_k) lane.partial.reserve((size_t)std::max(1ll, chunk*plan.partial_slots*64*points));
         if (rq.evals != nullptr)
         {
             lane.evals.reserve(1);
@@ -587,6 +674,9 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.core = lane.core.data;
             args.schedule = lane.schedule.data;
             args.levels = lane.levels.data;
+            args.items = plan.items.data;
+            args.partial = lane.partial.data;
+            args.partial_slots = plan.partial_slots;
             args.level_stride = sums_stride;
             args.k = sums;
             args.n_lines = n_lines;
@@ -602,9 +692,17 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.ablate = engine->ablate;
 
             engine->timed(kTimeAccumulate, stream, [&] {
-                // One workgroup per tile, padded to a multiple of 8 for the XCD mapping.
-                dim3 grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
+                // One workgroup per work item, heaviest items first.
+                dim3 grid((unsigned)plan.n_items, (unsigned)count);
                 launch_accumulate(points, grid, stream, args);
+                if (plan.n_split > 0)
+                {
+                    const int units = plan.n_split*points;      // (split tile, 64-point row)
+                    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((units + 3)/4), (unsigned)count),
+                                       dim3(256), 0, stream, args, plan.split.data, plan.n_split,
+                                       64*points);
+                    HIP_TRY(hipGetLastError());
+                }
             });
 
             if (with_pedestal)
