@@ -129,7 +129,7 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 // Per row the decisions are wave-uniform: skip (outside the window), Lorentz (whole row in
 // the far wing), or core.  In a core row every lane applies the reference's chain on
 // xi = (v-nu')*repwid (voigt.c:76-84): region 0 and w4 region 1 (voigt.c:95-96) are
-// evaluated inline; only lanes closer to the centre than xlim1 call wells_profile().
+// evaluated inline; only lanes closer to the centre than xlim1 call wells_inner().
 template <int P>
 __device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
                                              int i0, int i1, int lane,
@@ -185,7 +185,7 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
             }
             if (!far && !mid)
             {
-                value = c.amp*wells_profile(xi, c.y);
+                value = c.amp*wells_inner(xi, c.y);
             }
         }
         acc[p] += inside ? value : 0.;

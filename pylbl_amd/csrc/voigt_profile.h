@@ -9,9 +9,10 @@
 //                    amplitude of voigt.c:188 and x = (v-nu')*repwid, y = repwid*gamma this
 //                    is S*gamma/pi / ((v-nu')^2 + gamma^2): no repwid, one reciprocal.
 //                    The same expression is the y >= 70.55 branch (voigt.c:17-27).
-//   wells_profile()  everything else, the reference's chain evaluated per point with the
-//                    reference's operation order (this file is compiled with
-//                    -ffp-contract=off; only the far wing uses explicit fma).
+//   wells_inner()    the points nearer to the centre than xlim1 (w4 regions 2-3, CPF12),
+//   wells_profile()  the whole chain for one point.  Region SELECTION is the reference's,
+//                    comparison for comparison (this file is compiled with
+//                    -ffp-contract=off); values use reciprocal + Newton instead of division.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -56,43 +57,26 @@ __device__ __forceinline__ double lorentz_four(double v,
     return __builtin_fma(num, rcp_newton(t12*t34), sum);
 }
 
-// K(x,y) for y < 70.55 exactly as voigt.c:74-187 selects and evaluates it.
-// Not inlined: it is reached for well under 1 % of the evaluations and would otherwise be
-// replicated for every unrolled point of the tile.
-__device__ __noinline__ double wells_profile(double xi, double y)
+// K(x,y) for the points nearer to the line centre than xlim1 (w4 regions 2 and 3, CPF12
+// regions I and II), selected exactly as voigt.c:98-186 selects them (same comparisons on
+// the same abx and limits).  Values: the reference's expressions with its divisions replaced
+// by reciprocal + Newton step (1.4e-15), far inside the 1e-6 parity bar.
+// Not inlined: reached by a few rows per line only, and large.
+__device__ __noinline__ double wells_inner(double xi, double y)
 {
-    const double rsqrpi = 1./sqrt(kPi);
+    const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
     const double y0 = 1.5;
     const double y0py0 = y0 + y0;
     const double y0q = y0*y0;
     const double yq = y*y;
-    const double yrrtpi = y*rsqrpi;
-    const double xlim0 = sqrt(15100. + y*(40. - y*3.6));
-    double xlim1 = (y >= 8.425) ? 0. : sqrt(164. - y*(4.3 + y*1.8));
-    double xlim2 = 6.8 - y;
+    // voigt.c:44-53: for y <= 1e-6 the w4 regions 1 and 2 are switched off.
+    const double xlim2 = (y <= 0.000001) ? 1.e300 : 6.8 - y;
     const double xlim3 = 2.4*y;
     const double xlim4 = 18.1*y + 1.65;
-    if (y <= 0.000001)
-    {
-        xlim1 = xlim0;
-        xlim2 = xlim0;
-    }
     const double abx = fabs(xi);
     const double xq = abx*abx;
     double buf;
-    if (abx >= xlim0)
-    {
-        buf = yrrtpi/(xq + yq);
-    }
-    else if (abx >= xlim1)
-    {
-        const double a0 = yq + 0.5;
-        const double d0 = a0*a0;
-        const double d2 = yq + yq - 1.;
-        const double d = rsqrpi/(d0 + xq*(d2 + xq));
-        buf = d*y*(a0 + xq);
-    }
-    else if (abx >= xlim2)
+    if (abx >= xlim2)
     {
         const double h0 = 0.5625 + yq*(4.5 + yq*(10.5 + yq*(6.0 + yq)));
         const double h2 = -4.5 + yq*(9.0 + yq*(6.0 + yq*4.0));
@@ -101,7 +85,7 @@ __device__ __noinline__ double wells_profile(double xi, double y)
         const double e0 = 1.875 + yq*(8.25 + yq*(5.5 + yq));
         const double e2 = 5.25 + yq*(1.0 + yq*3.0);
         const double e4 = 0.75*h6;
-        const double d = rsqrpi/(h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
+        const double d = rsqrpi*rcp_newton(h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
         buf = d*y*(e0 + xq*(e2 + xq*(e4 + xq)));
     }
     else if (abx < xlim3)
@@ -127,7 +111,7 @@ __device__ __noinline__ double wells_profile(double xi, double y)
                           + y*(12.79568 + y*1.9099744))));
         const double p6 = -0.07272979 + y*(0.9377051 + y*(4.266322 + y*1.273316));
         const double p8 = 0.0005480304 + y*0.3183291;
-        const double d = 1.7724538/(z0 + xq*(z2 + xq*(z4 + xq*(z6 + xq*(z8 + xq)))));
+        const double d = 1.7724538*rcp_newton(z0 + xq*(z2 + xq*(z4 + xq*(z6 + xq*(z8 + xq)))));
         buf = d*(p0 + xq*(p2 + xq*(p4 + xq*(p6 + xq*p8))));
     }
     else
@@ -148,12 +132,12 @@ __device__ __noinline__ double wells_profile(double xi, double y)
         {
             double d = xi - tt[j];
             const double mq = d*d;
-            const double mf = 1./(mq + ypy0q);
+            const double mf = rcp_newton(mq + ypy0q);
             const double xm = mf*d;
             const double ym = mf*ypy0;
             d = xi + tt[j];
             const double pq = d*d;
-            const double pf = 1./(pq + ypy0q);
+            const double pf = rcp_newton(pq + ypy0q);
             const double xp = pf*d;
             const double yp = pf*ypy0;
             if (inner)
@@ -162,8 +146,8 @@ __device__ __noinline__ double wells_profile(double xi, double y)
             }
             else
             {
-                buf += (cc[j]*(mq*mf - y0*ym) + ss[j]*yf*xm)/(mq + y0q)
-                       + (cc[j]*(pq*pf - y0*yp) - ss[j]*yf*xp)/(pq + y0q);
+                buf += (cc[j]*(mq*mf - y0*ym) + ss[j]*yf*xm)*rcp_newton(mq + y0q)
+                       + (cc[j]*(pq*pf - y0*yp) - ss[j]*yf*xp)*rcp_newton(pq + y0q);
             }
         }
         if (!inner)
@@ -172,6 +156,31 @@ __device__ __noinline__ double wells_profile(double xi, double y)
         }
     }
     return buf;
+}
+
+// K(x,y) for y < 70.55 with the reference's full region chain (voigt.c:74-187): used where
+// a single point is evaluated at a time (the pedestal slots).
+__device__ __forceinline__ double wells_profile(double xi, double y)
+{
+    const double rsqrpi = 0.56418958354775628695;
+    const double yq = y*y;
+    const double xlim0 = sqrt(15100. + y*(40. - y*3.6));
+    double xlim1 = (y >= 8.425) ? 0. : sqrt(164. - y*(4.3 + y*1.8));
+    if (y <= 0.000001) xlim1 = xlim0;
+    const double abx = fabs(xi);
+    const double xq = abx*abx;
+    if (abx >= xlim0)
+    {
+        return y*rsqrpi*rcp_newton(xq + yq);
+    }
+    if (abx >= xlim1)
+    {
+        const double a0 = yq + 0.5;
+        const double d0 = a0*a0;
+        const double d2 = yq + yq - 1.;
+        return rsqrpi*rcp_newton(d0 + xq*(d2 + xq))*y*(a0 + xq);
+    }
+    return wells_inner(xi, y);
 }
 
 }  // namespace lbl
