@@ -124,6 +124,26 @@ def cpu_baseline(tables, atmos, v0, n_per_v, sample_cm, remove_pedestal):
     }
 
 
+def profiled_traffic(workload):
+    """HBM bytes per accumulate launch from the newest committed rocprofv3 counter summary
+    (profiles/*_summary.json, made by scripts/profile_bench.sh + summarize_profile.py: separate
+    FETCH_SIZE / WRITE_SIZE passes, KiB units, reads doubled per the gfx950 correction) -- only
+    if that profile ran this same workload; the counters cannot be read from inside bench.py."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+        try:
+            with open(path) as handle:
+                summary = json.load(handle)
+            if summary["bench_line"]["config"]["workload"] != workload:
+                continue
+            for name, counters in summary["counters"].items():
+                if "accumulate_kernel" in name and "hbm_bytes_per_launch" in counters:
+                    return counters["hbm_bytes_per_launch"], os.path.basename(path)
+        except (OSError, KeyError, TypeError, ValueError):
+            continue
+    return None, None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -273,6 +293,10 @@ def main():
                 "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
                 "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
         }
+        traffic, source = profiled_traffic(line["config"]["workload"])
+        if traffic is not None:
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_source"] = f"profiles/{source}"
         if args.ablate:
             line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
         if world == 1 and not args.no_cpu_baseline:
