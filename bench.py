@@ -56,6 +56,9 @@ def parse():
                         help="multiplies the HITRAN-like line counts")
     parser.add_argument("--points-per-lane", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                        help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo "
+                             "only to rehearse the multi-rank flow on fewer GPUs than ranks)")
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
@@ -169,9 +172,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback).")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     from pylbl_amd import synthetic
     from pylbl_amd.engine import Engine
@@ -185,7 +192,7 @@ def main():
     mine = slice(rank*levels_local, (rank + 1)*levels_local)
 
     tables = [synthetic.line_table(f, v_lo, v_hi, scale=args.line_scale) for f in molecules]
-    engine = Engine(local_rank)
+    engine = Engine(device_index)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
     if args.ablate:
@@ -194,9 +201,11 @@ def main():
 
     # Spectra stay in HBM: [molecule, level, n] per rank (torch only owns the memory).
     spectra = torch.empty((len(molecules), levels_local, n), dtype=torch.float64, device="cuda")
+    on_host = world > 1 and args.backend == "gloo"
     gathered = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(spectra) for _ in range(world)]
+        gathered = [torch.empty_like(spectra, device="cpu" if on_host else "cuda")
+                    for _ in range(world)]
 
     class Slot(object):
         def __init__(self, tensor):
@@ -215,7 +224,7 @@ def main():
                 total += result[1]
         if world > 1:
             engine.synchronize()
-            dist.gather(spectra, gathered, dst=0)
+            dist.gather(spectra.cpu() if on_host else spectra, gathered, dst=0)
         return total
 
     def fence():
@@ -239,7 +248,8 @@ def main():
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
 
-    stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
+                         device="cpu" if on_host else "cuda")
     if world > 1:
         worst = stats.clone()
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
@@ -267,7 +277,7 @@ def main():
                             f"({n} points), cut_off 25, remove_pedestal={args.pedestal}",
                 "lines": {t.formula: t.num_lines for t in tables},
                 "levels_total": levels_total, "parallelism": f"levels sharded over {world} GPU(s)"
-                + (", RCCL gather to rank 0 inside the step" if world > 1 else ""),
+                + (f", {args.backend} gather to rank 0 inside the step" if world > 1 else ""),
             },
             "evals_per_step": evals_per_step,
             "evals_per_s_per_gpu": value/world,
