@@ -56,6 +56,9 @@ def parse():
                         help="multiplies the HITRAN-like line counts")
     parser.add_argument("--points-per-lane", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--farfield", action="store_true",
+                        help="engine option farfield=1: distant lines through their power "
+                             "series (an algorithmic shortcut; not the default)")
     parser.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                         help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo "
                              "only to rehearse the multi-rank flow on fewer GPUs than ranks)")
@@ -195,6 +198,8 @@ def main():
     engine = Engine(device_index)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
+    if args.farfield:
+        engine.set_option("farfield", 1)
     if args.ablate:
         engine.set_option("ablate", args.ablate)
     handles = [engine.load(t) for t in tables]
@@ -274,7 +279,8 @@ def main():
             "config": {
                 "workload": f"BASELINE config '{args.config}': {levels_local} level(s) per GPU, "
                             f"{'+'.join(molecules)}, grid {v_lo:g}-{v_hi:g} cm-1 at {dv:g} cm-1 "
-                            f"({n} points), cut_off 25, remove_pedestal={args.pedestal}",
+                            f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
+                            + (", far-field series on" if args.farfield else ""),
                 "lines": {t.formula: t.num_lines for t in tables},
                 "levels_total": levels_total, "parallelism": f"levels sharded over {world} GPU(s)"
                 + (f", {args.backend} gather to rank 0 inside the step" if world > 1 else ""),

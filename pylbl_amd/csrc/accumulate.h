@@ -63,8 +63,19 @@ __host__ __device__ inline void tile_bounds(const Tiling & t, int tile, int n_pe
 struct alignas(32) TileSchedule
 {
     int lo, a1, c1, c2, a2, hi;
-    int pad0, pad1;
+    int f1, f2;         // [a1,f1) and [f2,a2): far enough for the series of farfield.h
 };
+
+// Centre of a tile in wavenumber: the expansion point of the far-field series.
+__host__ __device__ inline double tile_centre(int v0, double dv, long long i0, long long i1)
+{
+    const double v_lo = (double)v0 + (double)i0*dv;
+    const double v_hi = (double)v0 + (double)i1*dv;
+    return 0.5*(v_lo + v_hi);
+}
+
+constexpr int kFarTerms = 21;       // series order 20: truncation <= ~1.5e-11 relative at ratio 1/4
+constexpr double kFarRatio = 4.;    // far lines are at least 4 tile half-widths from the centre
 
 // One unit of work for a workgroup: part `part` of `parts` of tile `tile`'s lines.  Dense
 // spectral bands give some tiles many times the average number of lines; the host splits
@@ -85,6 +96,7 @@ struct AccumulateArgs
     const TileSchedule * schedule;  // [levels][n_tiles]
     const LevelScalars * levels;    // [levels]
     const WorkItem * items;         // [n_items]
+    const double * far_series;      // [levels][n_tiles][kFarTerms] or nullptr (farfield.h)
     double * partial;               // [levels][partial_slots][64*P] sums of split tiles
     long long partial_slots;
     double * k;                     // [levels][level_stride]
@@ -291,8 +303,9 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     g.count[1] = e - g.begin[1];
     share_of(sc.a2, sc.hi, piece, pieces, 1, g.begin[2], e);
     g.count[2] = e - g.begin[2];
-    share_of(sc.a1, sc.c1, piece, pieces, 4, fa0, fa1);
-    share_of(sc.c2, sc.a2, piece, pieces, 4, fb0, fb1);
+    // [a1,f1) and [f2,a2) are summed by the far-field series (empty when that is off).
+    share_of(sc.f1, sc.c1, piece, pieces, 4, fa0, fa1);
+    share_of(sc.c2, sc.f2, piece, pieces, 4, fb0, fb1);
     // Left-over lines of the far-wing ranges (fewer than four each) take the general path.
     g.begin[3] = fa0 + ((fa1 - fa0) & ~3);
     g.count[3] = (fa1 - fa0) & 3;
@@ -314,6 +327,23 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     }
     __syncthreads();
 
+    // Far-field series of this tile (added once per tile, by part 0): sum_k s_k u^k with
+    // u = v - tile centre.
+    const bool add_series = a.far_series != nullptr && item.part == 0;
+    const double * __restrict__ series = a.far_series +
+        ((long long)level*a.n_tiles + tile)*kFarTerms;
+    const double u0 = tile_centre(a.v0, a.dv, first_point, last_point);
+    auto series_at = [&](double vv) {
+        const double u = vv - u0;
+        double value = series[kFarTerms - 1];
+#pragma unroll
+        for (int k = kFarTerms - 2; k >= 0; --k)
+        {
+            value = __builtin_fma(value, u, series[k]);
+        }
+        return value;
+    };
+
     if (item.parts > 1)
     {
         // A split tile: plain sums to this item's slot; combine_kernel finishes.
@@ -322,8 +352,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         for (int p = wave; p < P; p += 4)
         {
             // Fixed order of the four partial sums: results do not depend on scheduling.
-            slot[p*64 + lane] = (partial[0][p][lane] + partial[1][p][lane]) +
-                                (partial[2][p][lane] + partial[3][p][lane]);
+            double value = (partial[0][p][lane] + partial[1][p][lane]) +
+                           (partial[2][p][lane] + partial[3][p][lane]);
+            if (add_series)
+            {
+                const int i = i0 + p*64 + lane;
+                value += series_at((double)a.v0 + (double)i*a.dv);
+            }
+            slot[p*64 + lane] = value;
         }
         return;
     }
@@ -341,6 +377,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         {
             double value = (partial[0][p][lane] + partial[1][p][lane]) +
                            (partial[2][p][lane] + partial[3][p][lane]);
+            if (add_series)
+            {
+                value += series_at((double)a.v0 + (double)i*a.dv);
+            }
             value *= scale;
             if (a.accumulate)
             {

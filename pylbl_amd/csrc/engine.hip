@@ -21,6 +21,7 @@
 
 #include "../../include/lbl_amd.h"
 #include "accumulate.h"
+#include "farfield.h"
 #include "line_prep.h"
 #include "pedestal.h"
 #include "tile_schedule.h"
@@ -102,7 +103,7 @@ struct Molecule
     // Work-item plans, one per (grid, cut_off, tiling) this molecule has been computed on.
     struct Plan
     {
-        int v0, vn, n_per_v, cut_off, points, aligned;
+        int v0, vn, n_per_v, cut_off, points, aligned, farfield;
         int n_items = 0, n_split = 0;
         long long partial_slots = 0;
         DeviceBuffer<WorkItem> items;
@@ -140,6 +141,7 @@ struct Lane
     DeviceBuffer<double> staging;   // spectra on their way to host memory
     DeviceBuffer<double> raw;       // un-pedestalled sums when the output must be added to
     DeviceBuffer<double> partial;   // partial sums of split tiles
+    DeviceBuffer<double> far_series; // [levels][tiles][kFarTerms]
     DeviceBuffer<double> derived;
     DeviceBuffer<unsigned long long> evals;
     PedestalWorkspace pedestal;
@@ -203,6 +205,7 @@ struct lbl_engine
     int ablate = 0;
     int aligned_tiles = 0;          // measured: no gain at 0.001 cm-1
     int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
+    int farfield = 0;               // sum distant lines by their power series (farfield.h)
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind; };
@@ -391,14 +394,15 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
     for (auto & p : m.plans)
     {
         if (p->v0 == g.v0 && p->vn == g.vn && p->n_per_v == g.n_per_v &&
-            p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned)
+            p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned &&
+            p->farfield == engine->farfield)
         {
             return *p;
         }
     }
     std::unique_ptr<Molecule::Plan> plan(new Molecule::Plan());
     plan->v0 = g.v0; plan->vn = g.vn; plan->n_per_v = g.n_per_v; plan->cut_off = g.cut_off;
-    plan->points = points; plan->aligned = tiling.aligned;
+    plan->points = points; plan->aligned = tiling.aligned; plan->farfield = engine->farfield;
     const int n_tiles = tiling.n_tiles;
     const std::vector<double> & nu = m.column[0];
     std::vector<long long> weight((size_t)n_tiles);
@@ -407,15 +411,23 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
     {
         long long i0, i1;
         tile_bounds(tiling, t, g.n_per_v, g.n, i0, i1);
-        const double lo = (double)((i0 + g.n_per_v - 1)/g.n_per_v + g.v0 - g.cut_off - 1) - 0.05;
-        const double hi = (double)(i1/g.n_per_v + g.v0 + g.cut_off) + 1.05;
+        double lo = (double)((i0 + g.n_per_v - 1)/g.n_per_v + g.v0 - g.cut_off - 1) - 0.05;
+        double hi = (double)(i1/g.n_per_v + g.v0 + g.cut_off) + 1.05;
+        if (engine->farfield)
+        {
+            // Only the lines near the tile are evaluated point by point.
+            const double u0 = tile_centre(g.v0, g.dv, i0, i1);
+            const double radius = kFarRatio*0.5*(double)(i1 - i0)*g.dv + 0.6;
+            lo = std::max(lo, u0 - radius);
+            hi = std::min(hi, u0 + radius);
+        }
         weight[t] = std::lower_bound(nu.begin(), nu.end(), hi) -
                     std::lower_bound(nu.begin(), nu.end(), lo);
         total += weight[t];
     }
     // Aim for ~16 items per workgroup slot of the chip (256 CUs x ~5 resident workgroups),
     // but never items smaller than 512 lines.
-    const long long target = std::max<long long>(512, total/(16*1280) + 1);
+    const long long target = std::max<long long>(engine->farfield ? 128 : 512, total/(16*1280) + 1);
     std::vector<WorkItem> items;
     std::vector<SplitTile> split;
     std::vector<long long> item_weight;
@@ -448,7 +460,6 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
     plan->items.upload(sorted.data(), sorted.size(), stream);
     plan->split.upload(split.data(), split.size(), stream);
     HIP_TRY(hipStreamSynchronize(stream));      // the host vectors go out of scope
-    (void)engine;
     m.plans.push_back(std::move(plan));
     return *m.plans.back();
 }
@@ -563,6 +574,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         lane.schedule.reserve((size_t)(chunk*n_tiles));
         if (want_k && !out_device) lane.staging.reserve((size_t)(chunk*n_long));
         if (with_pedestal && out_device && add_into) lane.raw.reserve((size_t)(chunk*n_long));
+        if (want_k && engine->farfield) lane.far_series.reserve((size_t)(chunk*n_tiles*kFarTerms));
         if (want_k) lane.partial.reserve((size_t)std::max(1ll, chunk*plan.partial_slots*64*points));
         if (rq.evals != nullptr)
         {
@@ -654,7 +666,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 dim3 grid((unsigned)((n_tiles + 255)/256), (unsigned)count);
                 hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, stream,
                                    m->d_column[0].data, (int)n_lines, lane.levels.data, g,
-                                   tiling, lane.schedule.data);
+                                   tiling, engine->farfield, lane.schedule.data);
                 HIP_TRY(hipGetLastError());
             });
 
@@ -675,6 +687,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.schedule = lane.schedule.data;
             args.levels = lane.levels.data;
             args.items = plan.items.data;
+            args.far_series = engine->farfield ? lane.far_series.data : nullptr;
             args.partial = lane.partial.data;
             args.partial_slots = plan.partial_slots;
             args.level_stride = sums_stride;
@@ -692,6 +705,14 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.ablate = engine->ablate;
 
             engine->timed(kTimeAccumulate, stream, [&] {
+                if (engine->farfield)
+                {
+                    dim3 far_grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
+                    hipLaunchKernelGGL(farfield_kernel, far_grid, dim3(256), 0, stream,
+                                       lane.wing.data, lane.schedule.data, n_lines, tiling, g.v0,
+                                       g.n_per_v, g.n, g.dv, lane.far_series.data);
+                    HIP_TRY(hipGetLastError());
+                }
                 // One workgroup per work item, heaviest items first.
                 dim3 grid((unsigned)plan.n_items, (unsigned)count);
                 launch_accumulate(points, grid, stream, args);
@@ -1038,6 +1059,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "timing" && (value == 0 || value == 1))
     {
         engine->timing = (int)value;
+    }
+    else if (key == "farfield" && (value == 0 || value == 1))
+    {
+        engine->farfield = (int)value;
     }
     else if (key == "overlap_pedestal" && (value == 0 || value == 1))
     {

@@ -116,6 +116,7 @@ __device__ inline int first_above(const double * __restrict__ nu, int n, double 
 __global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict__ nu, int n_lines,
                                                        const LevelScalars * __restrict__ levels,
                                                        const GridSpec g, const Tiling tiling,
+                                                       const int farfield,
                                                        TileSchedule * __restrict__ schedule)
 {
     const int tile = blockIdx.x*blockDim.x + threadIdx.x;
@@ -157,8 +158,22 @@ __global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict
     s.a2 = min(max(s.a2, s.a1), s.hi);
     s.c1 = min(max(s.c1, s.a1), s.a2);
     s.c2 = min(max(s.c2, s.c1), s.a2);
-    s.pad0 = 0;
-    s.pad1 = 0;
+    // Far-field split (farfield.h): lines at least kFarRatio half-widths from the tile
+    // centre, and beyond every possible core, go to the series; without it the ranges
+    // [a1,f1) and [f2,a2) are empty.
+    s.f1 = s.a1;
+    s.f2 = s.a2;
+    if (farfield && kk < 0.5)
+    {
+        const double half = 0.5*(v_hi - v_lo);
+        const double u0 = tile_centre(g.v0, g.dv, i0, i1);
+        const double core = kk*(v_hi + smax)/(1. - kk)*(1. + 1.e-9) + smax + 1.e-9;
+        const double radius = fmax(kFarRatio*half, core + half)*(1. + 1.e-9) + 1.e-6;
+        s.f1 = first_above(nu, n_lines, u0 - radius - smax);
+        s.f2 = first_not_below(nu, n_lines, u0 + radius + smax);
+        s.f1 = min(max(s.f1, s.a1), s.c1);
+        s.f2 = min(max(s.f2, s.c2), s.a2);
+    }
     schedule[(long long)level*n_tiles + tile] = s;
 }
 

@@ -204,3 +204,47 @@ def test_extreme_levels(engine, oracle):
             case = golden_io.Case("extreme", level, 0, 0, 0, 2000, 2051, 400, 25, ped, None, 0)
             assert_spectrum(k[level], k_ref, case, f"extreme level {level} ped={ped}")
     engine.free(molecule)
+
+
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+def test_farfield_series_option(engine, oracle, remove_pedestal):
+    """Option farfield=1 sums distant lines through their power series (farfield.h).  Same
+    1e-6 bar against the oracle; against the direct kernel the difference must stay at the
+    series' truncation level."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("CO2", 600., 700., num_lines=6000, seed=91)
+    atmos = synthetic.fixture_atmosphere()
+    v0, vn, npv = 610, 670, 1000
+    molecule = engine.load(table)
+    direct = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
+                            remove_pedestal=remove_pedestal)
+    engine.set_option("farfield", 1)
+    try:
+        for points in (0, 4, 2):
+            engine.set_option("points_per_lane", points)
+            k = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
+                               remove_pedestal=remove_pedestal)
+            if not remove_pedestal:
+                assert np.max(np.abs(k - direct)/direct) < 1.e-9
+            case = golden_io.Case("far", 0, 0, 0, 0, v0, vn, npv, 25, remove_pedestal, None, 0)
+            for level in (0, 3):
+                k_ref, _ = oracle.absorption_port(table, atmos.t[level], atmos.p[level],
+                                                  atmos.vmr["CO2"][level], v0, vn, npv,
+                                                  remove_pedestal=remove_pedestal)
+                assert_spectrum(k[level], k_ref, case, f"farfield P={points} level {level}")
+        # Golden vectors with the option on (coarser grids: few or no far lines).
+        engine.set_option("points_per_lane", 0)
+        for group in ("co2_band", "h2o_nir", "clipping", "h2o40"):
+            gtable, cases = golden_io.load_group(group)
+            gm = engine.load(gtable)
+            for c in cases:
+                if c.remove_pedestal != remove_pedestal:
+                    continue
+                kk = engine.compute(gm, c.temperature, c.pressure, c.vmr, c.v0, c.vn, c.n_per_v,
+                                    cut_off=c.cut_off, remove_pedestal=c.remove_pedestal)[0]
+                assert_spectrum(kk, c.k, c, f"farfield {group}[{c.index}]")
+            engine.free(gm)
+    finally:
+        engine.set_option("farfield", 0)
+        engine.set_option("points_per_lane", 0)
+    engine.free(molecule)
