@@ -50,6 +50,8 @@ def parse():
     parser.add_argument("--warmup", type=int, default=2)
     parser.add_argument("--config", default="target", choices=sorted(CONFIGS))
     parser.add_argument("--levels-per-gpu", type=int, default=1)
+    parser.add_argument("--profile", default="surface", choices=["surface", "standard"],
+                        help="atmosphere of multi-level runs (see atmosphere_for)")
     parser.add_argument("--pedestal", action="store_true",
                         help="remove_pedestal=True (the default through compute_absorption)")
     parser.add_argument("--line-scale", type=float, default=1.,
@@ -59,6 +61,9 @@ def parse():
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; not the default)")
+    parser.add_argument("--host-output", action="store_true",
+                        help="copy every spectrum back to host memory inside the step "
+                             "(PCIe-inclusive rate; never the headline value)")
     parser.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                         help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo "
                              "only to rehearse the multi-rank flow on fewer GPUs than ranks)")
@@ -70,12 +75,19 @@ def parse():
     return parser.parse_args()
 
 
-def atmosphere_for(levels_total):
-    """Level 0 is the reference's surface fixture level; the rest a standard atmosphere."""
+def atmosphere_for(levels_total, profile):
+    """profile "surface": every level is the reference's surface fixture level
+    (tests/conftest.py:61-77), so each GPU of a weak-scaling run gets exactly the same work;
+    "standard": level 0 is that level, the rest a standard atmosphere (lower pressures are
+    10-20 % slower per level: more evaluations fall in the inner Voigt regions)."""
     from pylbl_amd import synthetic
     surface = synthetic.surface_level()
     if levels_total == 1:
         return surface
+    if profile == "surface":
+        return synthetic.Atmos(p=np.repeat(surface.p, levels_total),
+                               t=np.repeat(surface.t, levels_total),
+                               vmr={k: np.repeat(v, levels_total) for k, v in surface.vmr.items()})
     standard = synthetic.standard_atmosphere(levels_total)
     t = standard.t.copy()
     p = standard.p.copy()
@@ -191,7 +203,7 @@ def main():
     n = (grid_vn - grid_v0)*n_per_v
     levels_local = args.levels_per_gpu
     levels_total = levels_local*world
-    atmos = atmosphere_for(levels_total)
+    atmos = atmosphere_for(levels_total, args.profile)
     mine = slice(rank*levels_local, (rank + 1)*levels_local)
 
     tables = [synthetic.line_table(f, v_lo, v_hi, scale=args.line_scale) for f in molecules]
@@ -217,13 +229,16 @@ def main():
             self.pointer = tensor.data_ptr()
             self.shape = tuple(tensor.shape)
 
+    host_spectra = np.empty((len(molecules), levels_local, n)) if args.host_output else None
+
     def step(count_evals=False):
         total = 0
         for m, handle in enumerate(handles):
             formula = molecules[m]
             result = engine.compute(handle, atmos.t[mine], atmos.p[mine], atmos.vmr[formula][mine],
                                     grid_v0, grid_vn, n_per_v, remove_pedestal=args.pedestal,
-                                    out=Slot(spectra[m]), asynchronous=True,
+                                    out=host_spectra[m] if args.host_output else Slot(spectra[m]),
+                                    asynchronous=not args.host_output,
                                     want_evals=count_evals)
             if count_evals:
                 total += result[1]
@@ -252,6 +267,28 @@ def main():
     elapsed = time.perf_counter() - start
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
+
+    # Not part of `value`: the same steps with the optional far-field series switched on.
+    farfield_extra = None
+    if world == 1 and not args.farfield and not args.ablate and not args.host_output:
+        engine.set_option("farfield", 1)
+        for _ in range(2):
+            step()
+        fence()
+        start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        far_elapsed = time.perf_counter() - start
+        engine.set_option("farfield", 0)
+        farfield_extra = {
+            "value": evals_per_step_local*args.steps/far_elapsed, "unit": "evals/s",
+            "ms_per_step": far_elapsed/args.steps*1e3,
+            "note": "engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 tile "
+                    "half-widths away are summed as one power series per tile (truncation "
+                    "<= ~1.5e-11 relative); same closed-form eval count; opt-in, parity-tested "
+                    "at the same 1e-6 bar",
+        }
 
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
                          device="cpu" if on_host else "cuda")
@@ -282,7 +319,7 @@ def main():
                             f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
                             + (", far-field series on" if args.farfield else ""),
                 "lines": {t.formula: t.num_lines for t in tables},
-                "levels_total": levels_total, "parallelism": f"levels sharded over {world} GPU(s)"
+                "levels_total": levels_total, "atmosphere": args.profile, "parallelism": f"levels sharded over {world} GPU(s)"
                 + (f", {args.backend} gather to rank 0 inside the step" if world > 1 else ""),
             },
             "evals_per_step": evals_per_step,
@@ -309,6 +346,10 @@ def main():
                 "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
                 "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
         }
+        if farfield_extra is not None:
+            line["farfield_option"] = farfield_extra
+        if args.host_output:
+            line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
         traffic, source = profiled_traffic(line["config"]["workload"])
         if traffic is not None:
             line["roofline"]["traffic"] = traffic

@@ -36,9 +36,14 @@ def library():
     if _library is not None:
         return _library
     if not LIBRARY_PATH.exists():
-        raise EngineError(
-            f"{LIBRARY_PATH} is missing: build it with `python -m pylbl_amd.build` "
-            "(there is no CPU fallback).")
+        # A fresh checkout: compile in-tree (hipcc cross-compiles without a GPU).
+        try:
+            from . import build
+            build.build()
+        except Exception as error:
+            raise EngineError(
+                f"{LIBRARY_PATH} is missing and could not be built ({error}); build it with "
+                "`python -m pylbl_amd.build` (there is no CPU fallback).")
     lib = CDLL(str(LIBRARY_PATH))
     f64p, i32p, i64p = POINTER(c_double), POINTER(c_int32), POINTER(c_int64)
     lib.lbl_engine_create.argtypes = [c_int32, POINTER(c_void_p)]
