@@ -81,7 +81,8 @@ class Gas(object):
 
     def absorption_coefficients(self, temperature, pressure, volume_mixing_ratio, grid,
                                 remove_pedestal=False, cut_off=25, range_policy="reference",
-                                out=None, scale_density=False, accumulate=False):
+                                out=None, scale_density=False, accumulate=False,
+                                asynchronous=False):
         """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v]."""
         if self._deferred_error is not None:
             raise self._deferred_error
@@ -94,7 +95,8 @@ class Gas(object):
         return self.engine.compute(self.molecule, temperature, pressure, volume_mixing_ratio,
                                    v0, vn, n_per_v, cut_off=cut_off,
                                    remove_pedestal=remove_pedestal, range_policy=range_policy,
-                                   out=out, scale_density=scale_density, accumulate=accumulate)
+                                   out=out, scale_density=scale_density, accumulate=accumulate,
+                                   asynchronous=asynchronous)
 
     def __del__(self):
         try:
