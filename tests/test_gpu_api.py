@@ -169,6 +169,43 @@ def test_asynchronous_pedestal_calls_share_the_gpu(oracle):
     e.close()
 
 
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+def test_level_chunking_and_strides(remove_pedestal):
+    """A tiny workspace budget forces several passes over the levels; results must not depend
+    on the chunking, on host vs device output, or on a padded level stride."""
+    from ctypes import c_int64, c_void_p
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CH4", 1200., 1400., num_lines=20000, seed=81,
+                                 tips_range=(150, 400))
+    h = e.load(table)
+    atmos = synthetic.standard_atmosphere(7)
+    v0, vn, npv = 1250, 1330, 200
+    n = (vn - v0)*npv
+    whole = e.compute(h, atmos.t, atmos.p, atmos.vmr["CH4"], v0, vn, npv,
+                      remove_pedestal=remove_pedestal)
+    e.set_option("workspace_bytes", 1 << 20)           # ~3 levels' worth -> several passes
+    chunked = e.compute(h, atmos.t, atmos.p, atmos.vmr["CH4"], v0, vn, npv,
+                        remove_pedestal=remove_pedestal)
+    assert np.array_equal(chunked, whole)
+    out = DeviceSpectra(e, 7, n)
+    e.compute(h, atmos.t, atmos.p, atmos.vmr["CH4"], v0, vn, npv,
+              remove_pedestal=remove_pedestal, out=out)
+    assert np.array_equal(out.to_host(), whole)
+    out.free()
+    # Padded host rows through the raw C ABI (level_stride > n).
+    stride = n + 37
+    padded = np.full((7, stride), -1.)
+    t, p, x = (np.ascontiguousarray(a, dtype=np.float64)
+               for a in (atmos.t, atmos.p, atmos.vmr["CH4"]))
+    rc = e.lib.lbl_compute(e.handle, h, 7, t.ctypes.data, p.ctypes.data, x.ctypes.data, v0, vn,
+                           npv, 25, int(remove_pedestal), 0, 0, c_void_p(padded.ctypes.data),
+                           c_int64(stride), None)
+    assert rc == 0
+    assert np.array_equal(padded[:, :n], whole) and np.all(padded[:, n:] == -1.)
+    e.close()
+
+
 def test_error_paths():
     from pylbl_amd.engine import Engine
     from pylbl_amd.errors import EngineError
