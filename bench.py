@@ -58,6 +58,9 @@ def parse():
                         help="multiplies the HITRAN-like line counts")
     parser.add_argument("--points-per-lane", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-extras", action="store_true",
+                        help="only the timed steps: no CPU baseline, no far-field extra pass "
+                             "(what scripts/profile_bench.sh runs under rocprofv3)")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; not the default)")
@@ -270,7 +273,8 @@ def main():
 
     # Not part of `value`: the same steps with the optional far-field series switched on.
     farfield_extra = None
-    if world == 1 and not args.farfield and not args.ablate and not args.host_output:
+    if world == 1 and not args.farfield and not args.ablate and not args.host_output and \
+            not args.no_extras:
         engine.set_option("farfield", 1)
         for _ in range(2):
             step()
@@ -356,7 +360,7 @@ def main():
             line["roofline"]["traffic_source"] = f"profiles/{source}"
         if args.ablate:
             line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, n_per_v,
                                                 args.cpu_sample_cm, args.pedestal)
         print(json.dumps(line))

@@ -74,8 +74,12 @@ __host__ __device__ inline double tile_centre(int v0, double dv, long long i0, l
     return 0.5*(v_lo + v_hi);
 }
 
-constexpr int kFarTerms = 21;       // series order 20: truncation <= ~1.5e-11 relative at ratio 1/4
-constexpr double kFarRatio = 4.;    // far lines are at least 4 tile half-widths from the centre
+#ifndef LBL_FAR_TERMS
+#define LBL_FAR_TERMS 21
+#define LBL_FAR_RATIO 4.
+#endif
+constexpr int kFarTerms = LBL_FAR_TERMS;     // series order 20: truncation <= ~1.5e-11 relative at ratio 1/4
+constexpr double kFarRatio = LBL_FAR_RATIO;  // far lines are at least 4 tile half-widths from the centre
 
 // One unit of work for a workgroup: part `part` of `parts` of tile `tile`'s lines.  Dense
 // spectral bands give some tiles many times the average number of lines; the host splits
