@@ -74,6 +74,9 @@ __host__ __device__ inline double tile_centre(int v0, double dv, long long i0, l
     return 0.5*(v_lo + v_hi);
 }
 
+#ifndef LBL_WING_GROUP
+#define LBL_WING_GROUP 8        // far-wing lines per reciprocal: 4 or 8
+#endif
 #ifndef LBL_FAR_TERMS
 #define LBL_FAR_TERMS 21
 #define LBL_FAR_RATIO 4.
@@ -128,7 +131,29 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 {
     const int qa = (a1 - a0) >> 2;
     const int quads = qa + ((b1 - b0) >> 2);
-    for (int q = 0; q < quads; ++q)
+    int q = 0;
+#if LBL_WING_GROUP == 8
+    // Two groups of four per step: eight lines share one reciprocal.
+    for (; q + 2 <= quads; q += 2)
+    {
+        const int ja = q < qa ? a0 + 4*q : b0 + 4*(q - qa);
+        const int jb = (q + 1) < qa ? a0 + 4*(q + 1) : b0 + 4*(q + 1 - qa);
+        WingTerm l[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const LineWing wa = wing[ja + i], wb = wing[jb + i];
+            l[i] = WingTerm{wa.centre, wa.g2, wa.bl};
+            l[4 + i] = WingTerm{wb.centre, wb.g2, wb.bl};
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+        {
+            acc[p] = lorentz_eight(v[p], l, acc[p]);
+        }
+    }
+#endif
+    for (; q < quads; ++q)
     {
         const int j = q < qa ? a0 + 4*q : b0 + 4*(q - qa);
         const LineWing l1 = wing[j], l2 = wing[j + 1], l3 = wing[j + 2], l4 = wing[j + 3];

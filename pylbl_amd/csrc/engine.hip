@@ -375,7 +375,9 @@ int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & ti
     int p = forced;
     if (!is_forced)
     {
-        p = n_per_v >= 400 ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
+        // Measured on the 0.001 cm-1 workload: 4 is ~2 % ahead of 8 for the direct kernel,
+        // 8 is ahead when the far-field series carries most lines.
+        p = (n_per_v >= 400 && engine->farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
     }
     tiling.aligned = 0;
     tiling.per_cell = 0;

@@ -57,6 +57,36 @@ __device__ __forceinline__ double lorentz_four(double v,
     return __builtin_fma(num, rcp_newton(t12*t34), sum);
 }
 
+// Eight far-wing lines at one point with a single reciprocal (two levels more of the same
+// pairing): 40 FMA-class operations + 1 v_rcp_f64 per 8 evaluations.
+struct WingTerm
+{
+    double centre, g2, bl;
+};
+
+__device__ __forceinline__ void wing_pair(double v, const WingTerm & p, const WingTerm & q,
+                                          double & num, double & den)
+{
+    const double d1 = v - p.centre, d2 = v - q.centre;
+    const double t1 = __builtin_fma(d1, d1, p.g2);
+    const double t2 = __builtin_fma(d2, d2, q.g2);
+    num = __builtin_fma(p.bl, t2, q.bl*t1);
+    den = t1*t2;
+}
+
+__device__ __forceinline__ double lorentz_eight(double v, const WingTerm (&l)[8], double sum)
+{
+    double n12, t12, n34, t34, n56, t56, n78, t78;
+    wing_pair(v, l[0], l[1], n12, t12);
+    wing_pair(v, l[2], l[3], n34, t34);
+    wing_pair(v, l[4], l[5], n56, t56);
+    wing_pair(v, l[6], l[7], n78, t78);
+    const double na = __builtin_fma(n12, t34, n34*t12), ta = t12*t34;
+    const double nb = __builtin_fma(n56, t78, n78*t56), tb = t56*t78;
+    const double num = __builtin_fma(na, tb, nb*ta);
+    return __builtin_fma(num, rcp_newton(ta*tb), sum);
+}
+
 // K(x,y) for the points nearer to the line centre than xlim1 (w4 regions 2 and 3, CPF12
 // regions I and II), selected exactly as voigt.c:98-186 selects them (same comparisons on
 // the same abx and limits).  Values: the reference's expressions with its divisions replaced
