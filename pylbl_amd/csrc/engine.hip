@@ -206,6 +206,7 @@ struct lbl_engine
     int aligned_tiles = 0;          // measured: no gain at 0.001 cm-1
     int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
+    int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind; };
@@ -739,7 +740,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 }
                 engine->timed(kTimePedestal, ped_stream, [&] {
                     pedestal_pass(lane.pedestal, ped_stream, m->view(), lane.wing.data,
-                                  lane.core.data, g, count, n_cells);
+                                  lane.core.data, g, count, n_cells, engine->scan_chain != 0);
                 });
                 if (engine->overlap_pedestal)
                 {
@@ -1061,6 +1062,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "timing" && (value == 0 || value == 1))
     {
         engine->timing = (int)value;
+    }
+    else if (key == "scan_chain" && (value == 0 || value == 1))
+    {
+        engine->scan_chain = (int)value;
     }
     else if (key == "farfield" && (value == 0 || value == 1))
     {

@@ -53,6 +53,16 @@ struct RunMeta
     int pad;
 };
 
+struct alignas(16) RunLink
+{
+    double ks;          // GS + VS: first-slot candidate before subtracting earlier pedestals
+    double ke;          // GE + VE: last-slot candidate
+    unsigned long long mask_s;  // bit j: run r-1-j holds this run's first slot in its window
+    unsigned long long mask_e;  // bit j: run r-1-j holds this run's last slot
+    int bin, pad0;
+    long long pad1;
+};
+
 template <typename T>
 struct RawBuffer
 {
@@ -83,6 +93,9 @@ struct PedestalWorkspace
     RawBuffer<int> run_count;       // [levels]
     RawBuffer<RunMeta> runs;        // [levels][max_runs]
     RawBuffer<double> slot_sums;    // [levels][max_runs][slot_stride]
+    RawBuffer<RunLink> links;       // [levels][max_runs]
+    RawBuffer<int> prefix_last;     // [levels][max_runs]
+    RawBuffer<int> regular;         // [levels] 1: monotone windows, fast chain
     RawBuffer<double> slots;        // [levels][cells+1]       (only when LDS is too small)
     RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]
     RawBuffer<double> cell_sum;     // [levels][cells]
@@ -289,12 +302,266 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fast chain: the recurrence in the pedestals alone.
+//
+// The value accumulated on a slot c before run r is
+//     sum_{q<r, c in W_q} G_q[c]  -  sum_{q<r, c in W_q} P_q
+// (G: profile sums of run q on its slots, W_q its window, P_q the sum of its pedestals), so
+//     P_r = min( GS_r + VS_r - sum_{q<r} P_q [fs_r in W_q] ,  GE_r + VE_r - sum_{q<r} P_q [ls_r in W_q] )
+// with fs_r / ls_r the run's end slots and VS / VE its own end values.  Which earlier runs
+// hold a slot, and the G sums, do not depend on the pedestals: run_links_kernel finds them in
+// parallel (bit masks over the previous 64 runs).  What is left is a recurrence in the P's.
+// Take a block of consecutive runs in which every earlier in-block run holds the later runs'
+// first slots, and holds either all or none of their last slots.  With L_r the in-block
+// prefix sum of P,
+//     L_r = min(Ks_r, L_{r-1} + Ke_r)     (no in-block run holds the last slot), or
+//     L_r = min(Ks_r, Ke_r)               (all of them do),
+// Ks/Ke being the candidates minus the pedestals of covering runs BEFORE the block: a first-
+// order recurrence in the (min,+) semiring, i.e. one wavefront scan per block of up to 32
+// runs instead of one serial step per run.  Blocks end where the pattern breaks (a window
+// that steps backwards: a few dozen places in a 5 000-window spectrum).  Levels where some
+// slot is shared by runs more than 64 apart (rows far out of order) keep run_chain_kernel.
+// ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double read_lane(double value, int lane)
 {
     const long long bits = __double_as_longlong(value);
     const int lo = __builtin_amdgcn_readlane((int)bits, lane);
     const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+constexpr int kLinkReach = 64;      // history visible to a run: the previous 64 runs
+
+// prefix_last[r] = max over q <= r of the runs' last slots (one 1024-thread block per level).
+__global__ __launch_bounds__(1024) void run_prefix_kernel(const int * __restrict__ run_count,
+                                                          int max_runs,
+                                                          const RunMeta * __restrict__ runs,
+                                                          int * __restrict__ prefix_last)
+{
+    __shared__ int wave_max[16];
+    __shared__ int carry;
+    const int level = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int count = run_count[level];
+    const RunMeta * meta = runs + (long long)level*max_runs;
+    int * out = prefix_last + (long long)level*max_runs;
+    if (threadIdx.x == 0) carry = -1;
+    __syncthreads();
+    for (int base = 0; base < count; base += 1024)
+    {
+        const int r = base + threadIdx.x;
+        int value = r < count ? meta[r].last_slot : -1;
+        for (int offset = 1; offset < 64; offset <<= 1)
+        {
+            const int up = __shfl_up(value, offset, 64);
+            if (lane >= offset) value = max(value, up);
+        }
+        if (lane == 63) wave_max[wave] = value;
+        __syncthreads();
+        int before = carry;
+        for (int i = 0; i < wave; ++i) before = max(before, wave_max[i]);
+        value = max(value, before);
+        if (r < count) out[r] = value;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = value;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void run_links_kernel(const int * __restrict__ run_count,
+                                                        int max_runs, int slot_stride,
+                                                        const RunMeta * __restrict__ runs,
+                                                        const double * __restrict__ slot_sums,
+                                                        const int * __restrict__ prefix_last,
+                                                        RunLink * __restrict__ links,
+                                                        int * __restrict__ regular)
+{
+    const int level = blockIdx.y;
+    const int r = blockIdx.x*blockDim.x + threadIdx.x;
+    const int count = run_count[level];
+    if (r >= count) return;
+    const RunMeta * meta = runs + (long long)level*max_runs;
+    const double * sums = slot_sums + (long long)level*max_runs*slot_stride;
+    const RunMeta m = meta[r];
+    // Nothing older than the visible history may hold one of this run's end slots.
+    if (r > kLinkReach &&
+        prefix_last[(long long)level*max_runs + r - kLinkReach - 1] >= m.first_slot)
+    {
+        atomicAnd(&regular[level], 0);
+    }
+    double gs = 0., ge = 0.;
+    unsigned long long mask_s = 0, mask_e = 0;
+    for (int j = 0; j < kLinkReach && r - 1 - j >= 0; ++j)
+    {
+        const int q = r - 1 - j;
+        const RunMeta e = meta[q];
+        if (e.first_slot <= m.first_slot && m.first_slot <= e.last_slot)
+        {
+            mask_s |= 1ull << j;
+            gs += sums[(long long)q*slot_stride + (m.first_slot - e.first_slot)];
+        }
+        if (e.first_slot <= m.last_slot && m.last_slot <= e.last_slot)
+        {
+            mask_e |= 1ull << j;
+            ge += sums[(long long)q*slot_stride + (m.last_slot - e.first_slot)];
+        }
+    }
+    RunLink link;
+    link.ks = gs + m.vs;
+    link.ke = ge + (m.vs - m.d);
+    link.mask_s = mask_s;
+    link.mask_e = mask_e;
+    link.bin = m.bin;
+    link.pad0 = 0;
+    link.pad1 = 0;
+    links[(long long)level*max_runs + r] = link;
+}
+
+__device__ __forceinline__ double shuffle_up(double value, int offset)
+{
+    return __shfl_up(value, offset, 64);
+}
+
+constexpr int kScanBlock = 32;      // runs per (min,+) scan
+constexpr int kLinkChunk = 256;     // run links staged in LDS at a time
+
+// One wavefront per level; only acts on levels run_links_kernel left flagged regular.
+__global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restrict__ run_count,
+                                                            int max_runs, int n_bins,
+                                                            const RunLink * __restrict__ links,
+                                                            const int * __restrict__ regular,
+                                                            double * __restrict__ bin_sum)
+{
+    extern __shared__ double lds[];
+    const int level = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!regular[level]) return;
+    // The chain is the critical path of the pedestal pass and shares its SIMD with
+    // accumulate wavefronts: let the arbiter prefer it.
+    __builtin_amdgcn_s_setprio(3);
+    double * bins = lds;                                    // [n_bins]
+    double * history = bins + n_bins;                       // pedestals of the last 128 runs
+    RunLink * staged = reinterpret_cast<RunLink *>(history + 128);   // [kLinkChunk]
+    for (int s = lane; s < n_bins; s += 64) bins[s] = 0.;
+    for (int s = lane; s < 128; s += 64) history[s] = 0.;
+    const int count = run_count[level];
+    const RunLink * link = links + (long long)level*max_runs;
+    const double inf = __builtin_inf();
+    int staged_from = 0, staged_to = 0;
+    __syncthreads();
+    int b = 0;
+    while (b < count)
+    {
+        if (b + kScanBlock > staged_to && staged_to < count)
+        {
+            // Stage the next chunk of links (coalesced) so that the serial part reads LDS.
+            staged_from = b;
+            staged_to = min(count, b + kLinkChunk);
+            for (int i = lane; i < staged_to - staged_from; i += 64)
+            {
+                staged[i] = link[staged_from + i];
+            }
+            __syncthreads();
+        }
+        const int r = b + lane;
+        const bool candidate = lane < kScanBlock && r < staged_to;
+        RunLink mine;
+        mine.ks = mine.ke = 0.;
+        mine.mask_s = mine.mask_e = 0;
+        mine.bin = -1;
+        if (candidate) mine = staged[r - staged_from];
+        // In-block part of the masks: bit j < lane is run r-1-j >= b.
+        const unsigned long long in_block = lane == 0 ? 0ull : ((1ull << lane) - 1ull);
+        const bool first_held = (mine.mask_s & in_block) == in_block;
+        const bool last_free = (mine.mask_e & in_block) == 0ull;
+        const bool last_held = (mine.mask_e & in_block) == in_block;
+        const bool fits = candidate && first_held && (last_free || last_held);
+        const unsigned long long fit_mask = __ballot(fits);
+        const int size = __builtin_ctzll(~fit_mask);        // leading run of ones (>= 1)
+        const bool active = lane < size;
+
+        // Pedestals of covering runs before the block.  History entry t is run b-1-t, which
+        // is bit t + lane of this lane's masks; lane t keeps entry t in a register.
+        const unsigned long long old_s = active ? mine.mask_s >> lane : 0ull;
+        const unsigned long long old_e = active ? mine.mask_e >> lane : 0ull;
+        const double entry = b - 1 - lane >= 0 ? history[(b - 1 - lane) & 127] : 0.;
+        double prev_s = 0., prev_e = 0.;
+        // Usual case: the covering runs are the most recent J ones (masks 0..01..1), so the
+        // sums are prefix sums of the history.
+        const bool contiguous = ((old_s & (old_s + 1ull)) | (old_e & (old_e + 1ull))) == 0ull;
+        if (__ballot(!contiguous) == 0ull)
+        {
+            double prefix = entry;
+            for (int offset = 1; offset < 64; offset <<= 1)
+            {
+                const double up = shuffle_up(prefix, offset);
+                if (lane >= offset) prefix += up;
+            }
+            const int count_s = __builtin_popcountll(old_s), count_e = __builtin_popcountll(old_e);
+            const double at_s = __shfl(prefix, (count_s - 1) & 63, 64);
+            const double at_e = __shfl(prefix, (count_e - 1) & 63, 64);
+            prev_s = count_s ? at_s : 0.;
+            prev_e = count_e ? at_e : 0.;
+        }
+        else
+        {
+            // Arbitrary masks: walk the history up to the farthest entry any lane needs.
+            const unsigned long long both = old_s | old_e;
+            int reach = both ? 64 - __builtin_clzll(both) : 0;
+            for (int offset = 32; offset > 0; offset >>= 1)
+            {
+                reach = max(reach, __shfl_xor(reach, offset, 64));
+            }
+            for (int t = 0; t < reach; ++t)
+            {
+                const double p = read_lane(entry, t);
+                if ((old_s >> t) & 1ull) prev_s += p;
+                if ((old_e >> t) & 1ull) prev_e += p;
+            }
+        }
+
+        // Element of the (min,+) scan: L_r = min(L_{r-1} + a, c).
+        double a = 0., c = inf;      // identity (right of the block)
+        if (active)
+        {
+            const double k_s = mine.ks - prev_s;
+            const double k_e = mine.ke - prev_e;
+            if (last_held && lane > 0)
+            {
+                a = inf;
+                c = fmin(k_s, k_e);
+            }
+            else
+            {
+                a = k_e;
+                c = k_s;
+            }
+        }
+        for (int offset = 1; offset < kScanBlock; offset <<= 1)
+        {
+            const double a_left = shuffle_up(a, offset);
+            const double c_left = shuffle_up(c, offset);
+            if (lane >= offset)
+            {
+                c = fmin(c_left + a, c);
+                a = a_left + a;
+            }
+        }
+        const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
+        double before = shuffle_up(total, 1);
+        if (lane == 0) before = 0.;
+        const double pedestal = total - before;
+        if (active)
+        {
+            history[r & 127] = pedestal;
+            if (mine.bin >= 0 && mine.bin < n_bins) atomicAdd(&bins[mine.bin], pedestal);
+        }
+        __syncthreads();
+        b += size;
+    }
+    __syncthreads();
+    for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = bins[s];
 }
 
 constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at a time
@@ -309,12 +576,15 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
                                                        GridSpec g, int n_cells, int n_bins,
                                                        const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
+                                                       const int * __restrict__ regular,
                                                        double * __restrict__ global_slots,
                                                        double * __restrict__ bin_sum)
 {
     extern __shared__ double lds[];
     const int level = blockIdx.x;
     const int lane = threadIdx.x;
+    if (regular != nullptr && regular[level]) return;    // run_chain_scan_kernel took it
+    __builtin_amdgcn_s_setprio(3);
     // LDS carve: [2 x staged slot sums][slots][bin sums]; without LDS room the last two are in HBM.
     double * staged = lds;
     double * a = USE_LDS ? lds + 2*kChainChunk*slot_stride
@@ -497,9 +767,15 @@ __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __re
 
 // Runs the whole pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are
 // already in HBM; leaves cell_sum / point_sum for the accumulate kernel's epilogue.
+__global__ void fill_int_kernel(int * data, int n, int value)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i < n) data[i] = value;
+}
+
 inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                           const LineWing * wing, const LineCore * core, const GridSpec & g,
-                          int count, int n_cells)
+                          int count, int n_cells, bool scan_chain = true)
 {
     auto check = [](hipError_t status, const char * what) {
         if (status != hipSuccess)
@@ -538,6 +814,35 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
                        ws.run_start.data, ws.run_count.data, max_runs, slot_stride,
                        ws.runs.data, ws.slot_sums.data);
     check(hipGetLastError(), "run_sums_kernel");
+    // Fast chain where the windows are monotone (flag per level), serial chain otherwise.
+    ws.links.reserve((size_t)count*max_runs);
+    ws.regular.reserve((size_t)count);
+    const bool try_scan = scan_chain && n_bins*sizeof(double) + 128*sizeof(double) +
+                          kLinkChunk*sizeof(RunLink) <= 150*1024;
+    check(hipMemsetAsync(ws.regular.data, 0, count*sizeof(int), stream), "regular flags");
+    if (try_scan)
+    {
+        hipLaunchKernelGGL(fill_int_kernel, dim3((count + 255)/256), dim3(256), 0, stream,
+                           ws.regular.data, count, 1);
+        ws.prefix_last.reserve((size_t)count*max_runs);
+        hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(1024), 0, stream,
+                           ws.run_count.data, max_runs, ws.runs.data, ws.prefix_last.data);
+        hipLaunchKernelGGL(run_links_kernel, dim3((max_runs + 255)/256, count), dim3(256), 0,
+                           stream, ws.run_count.data, max_runs, slot_stride, ws.runs.data,
+                           ws.slot_sums.data, ws.prefix_last.data, ws.links.data,
+                           ws.regular.data);
+        const size_t scan_lds = (size_t)(n_bins + 128)*sizeof(double) + kLinkChunk*sizeof(RunLink);
+        if (scan_lds > 64*1024)
+        {
+            check(hipFuncSetAttribute(reinterpret_cast<const void *>(run_chain_scan_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scan_lds), "LDS opt-in");
+        }
+        hipLaunchKernelGGL(run_chain_scan_kernel, dim3(count), dim3(64), scan_lds, stream,
+                           ws.run_count.data, max_runs, n_bins, ws.links.data, ws.regular.data,
+                           ws.bin_sum.data);
+        check(hipGetLastError(), "run_chain_scan_kernel");
+    }
     const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
     const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
     if (lds_bytes <= 160*1024 - 512)
@@ -550,14 +855,16 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
         }
         hipLaunchKernelGGL(run_chain_kernel<true>, dim3(count), dim3(64), lds_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, (double *)nullptr, ws.bin_sum.data);
+                           ws.runs.data, ws.slot_sums.data, ws.regular.data, (double *)nullptr,
+                           ws.bin_sum.data);
     }
     else
     {
         ws.slots.reserve((size_t)count*(n_cells + 1));
         hipLaunchKernelGGL(run_chain_kernel<false>, dim3(count), dim3(64), staged_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, ws.slots.data, ws.bin_sum.data);
+                           ws.runs.data, ws.slot_sums.data, ws.regular.data, ws.slots.data,
+                           ws.bin_sum.data);
     }
     check(hipGetLastError(), "run_chain_kernel");
     hipLaunchKernelGGL(pedestal_tables_kernel, dim3((n_cells + 255)/256, count), dim3(256), 0,
