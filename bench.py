@@ -246,8 +246,12 @@ def main():
             if count_evals:
                 total += result[1]
         if world > 1:
+            # The engine runs on its own streams: finish the spectra, gather them, and let the
+            # collective finish before the next step may overwrite the send buffer.
             engine.synchronize()
             dist.gather(spectra.cpu() if on_host else spectra, gathered, dst=0)
+            if not on_host:
+                torch.cuda.current_stream().synchronize()
         return total
 
     def fence():
