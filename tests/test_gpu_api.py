@@ -289,6 +289,23 @@ def test_full_size_linearity_additivity_determinism(full_size):
     e.free(hb)
 
 
+def test_full_size_farfield_option(full_size):
+    """At the benchmark size the opt-in far-field series must reproduce the direct kernel to
+    its truncation level (<= ~1.5e-11 by construction; 1e-9 asserted), at 1 atm and 10 Pa."""
+    e, tables, handles = full_size
+    v0, vn, npv = 1, 5001, 1000
+    try:
+        for formula, x in (("H2O", 6.6e-3), ("CO2", 3.6e-4)):
+            for t, p in ((288.99, 98388.), (232.7, 10.)):
+                e.set_option("farfield", 0)
+                direct = e.compute(handles[formula], t, p, x, v0, vn, npv)[0]
+                e.set_option("farfield", 1)
+                series = e.compute(handles[formula], t, p, x, v0, vn, npv)[0]
+                assert np.max(np.abs(series - direct)/direct) < 1.e-9, (formula, p)
+    finally:
+        e.set_option("farfield", 0)
+
+
 def test_full_size_pedestal_properties(full_size):
     """With the pedestal removed the spectrum stays >= 0 up to rounding, is <= the plain
     one, and levels in a batch do not influence each other."""
