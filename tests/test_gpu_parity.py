@@ -284,3 +284,37 @@ def test_pedestal_chain_variants_agree(engine, oracle):
             assert_spectrum(results[scan][level], k_ref, case, f"scan={scan} level {level}",
                             plain[level])
     engine.free(molecule)
+
+
+def test_empty_and_degenerate_inputs(engine, oracle):
+    """Empty table, a table with no line in reach of the grid, a single line, a one-cell grid,
+    a cut-off wider than the grid."""
+    from pylbl_amd import synthetic
+    base = synthetic.line_table("N2", 1., 400., num_lines=50, seed=99, tips_range=(150, 400))
+    empty = base.subset(np.zeros(base.num_lines, bool))
+    m = engine.load(empty)
+    for ped in (False, True):
+        k = engine.compute(m, 250., 5.e4, 0.78, 1, 41, 10, remove_pedestal=ped)
+        assert k.shape == (1, 400) and not k.any()
+    engine.free(m)
+    m = engine.load(base)
+    # Nothing within 26 cm-1 of the grid: the reference breaks at the first row -> zeros.
+    k = engine.compute(m, 250., 5.e4, 0.78, 1000, 1010, 10)
+    k_ref, _ = oracle.absorption_port(base, 250., 5.e4, 0.78, 1000, 1010, 10)
+    assert not k.any() and not k_ref.any()
+    k = engine.compute(m, 250., 5.e4, 0.78, 1000, 1010, 10, range_policy="skip")
+    assert not k.any()
+    engine.free(m)
+    single = base.subset(np.arange(base.num_lines) == 20)
+    m = engine.load(single)
+    v = int(single.nu[0])
+    for (v0, vn, npv, cut) in ((max(v - 30, 1), v + 30, 100, 25), (v, v + 1, 64, 25),
+                               (v, v + 1, 1, 25), (max(v - 3, 1), v + 3, 50, 100)):
+        for ped in (False, True):
+            k = engine.compute(m, 250., 5.e4, 0.78, v0, vn, npv, cut_off=cut, remove_pedestal=ped)[0]
+            k_ref, _ = oracle.absorption_port(single, 250., 5.e4, 0.78, v0, vn, npv, cut_off=cut,
+                                              remove_pedestal=ped)
+            k_plain, _ = oracle.absorption_port(single, 250., 5.e4, 0.78, v0, vn, npv, cut_off=cut)
+            case = golden_io.Case("single", 0, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
+            assert_spectrum(k, k_ref, case, f"single line {(v0, vn, npv, cut, ped)}", k_plain)
+    engine.free(m)
