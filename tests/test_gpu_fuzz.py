@@ -1,0 +1,78 @@
+"""Seeded random sweep of the whole argument space against the CPU oracle: grids, cut-offs,
+pressures from near-vacuum to 50 atm, row orders, tile sizes, pedestal on/off, far-field
+on/off, both line-scalar preparations."""
+import numpy as np
+import pytest
+
+from pylbl_amd import synthetic
+from tests import golden_io
+from tests.test_gpu_parity import assert_spectrum
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pylbl_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_case(engine, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    v0 = int(rng.integers(1, 3000))
+    span = int(rng.integers(1, 60))
+    vn = v0 + span
+    npv = int(rng.choice([1, 2, 7, 10, 33, 64, 100, 250, 1000]))
+    if span*npv > 40000:
+        span = max(40000//npv, 1)
+        vn = v0 + span
+    cut = int(rng.choice([25, 25, 25, 5, 60]))
+    lo, hi = max(v0 - cut - 1., 0.05), vn + cut + 1.
+    n_lines = int(rng.integers(1, 3000))
+    table = synthetic.line_table(str(rng.choice(["H2O", "CO2", "O3", "CH4"])), lo, hi,
+                                 num_lines=n_lines, seed=int(rng.integers(1 << 30)),
+                                 tips_range=(100, 900))
+    # Some lines exactly on grid points / integers, some duplicates, exaggerated shifts.
+    k = max(n_lines//10, 1)
+    table.nu[rng.choice(n_lines, k)] = np.round(table.nu[rng.choice(n_lines, k)])
+    table.delta_air *= float(rng.choice([0., 1., 5.]))
+    table.nu = np.clip(table.nu, lo, hi)
+    order = np.argsort(table.nu, kind="stable")
+    if rng.random() < 0.25:
+        order = rng.permutation(n_lines)            # rows out of order (range rule matters)
+    table = table.subset(order)
+    levels = int(rng.integers(1, 4))
+    t = rng.uniform(150., 800., levels)
+    p = 10.**rng.uniform(-2., 6.7, levels)
+    x = 10.**rng.uniform(-7., -0.5, levels)
+    ped = bool(rng.integers(0, 2))
+    policy = "skip" if rng.random() < 0.3 else "reference"
+    engine.set_option("farfield", int(rng.integers(0, 2)))
+    engine.set_option("prep", int(rng.random() < 0.2))
+    engine.set_option("points_per_lane", int(rng.choice([0, 0, 1, 2, 4, 8])))
+    engine.set_option("aligned_tiles", int(rng.random() < 0.3))
+    engine.set_option("scan_chain", int(rng.random() < 0.8))
+    molecule = engine.load(table)
+    try:
+        got = engine.compute(molecule, t, p, x, v0, vn, npv, cut_off=cut, remove_pedestal=ped,
+                             range_policy=policy)
+        source = table
+        if policy == "skip":
+            source = table.subset((table.nu >= v0 - (cut + 1)) & (table.nu <= vn + cut + 1))
+        for level in range(levels):
+            k_ref, _ = oracle.absorption_port(source, t[level], p[level], x[level], v0, vn, npv,
+                                              cut_off=cut, remove_pedestal=ped)
+            k_plain, _ = oracle.absorption_port(source, t[level], p[level], x[level], v0, vn, npv,
+                                                cut_off=cut)
+            case = golden_io.Case("fuzz", seed, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
+            assert_spectrum(got[level], k_ref, case,
+                            f"seed {seed} level {level}: v0={v0} vn={vn} npv={npv} cut={cut} "
+                            f"lines={n_lines} ped={ped} policy={policy} p={p[level]:.3g}", k_plain)
+    finally:
+        engine.free(molecule)
+        for name, value in (("farfield", 0), ("prep", 0), ("points_per_lane", 0),
+                            ("aligned_tiles", 0), ("scan_chain", 1)):
+            engine.set_option(name, value)
