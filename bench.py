@@ -219,13 +219,17 @@ def main():
         engine.set_option("ablate", args.ablate)
     handles = [engine.load(t) for t in tables]
 
-    # Spectra stay in HBM: [molecule, level, n] per rank (torch only owns the memory).
-    spectra = torch.empty((len(molecules), levels_local, n), dtype=torch.float64, device="cuda")
+    # Spectra stay in HBM: [molecule, level, n] per rank (torch only owns the memory).  Two
+    # buffers alternate so that the gather of one step (N > 1) runs beside the next step.
+    spectra = [torch.empty((len(molecules), levels_local, n), dtype=torch.float64, device="cuda")
+               for _ in range(2 if world > 1 else 1)]
     on_host = world > 1 and args.backend == "gloo"
-    gathered = None
+    gathered = [None, None]
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(spectra, device="cpu" if on_host else "cuda")
-                    for _ in range(world)]
+        gathered = [[torch.empty_like(spectra[0], device="cpu" if on_host else "cuda")
+                     for _ in range(world)] for _ in range(2)]
+    pending = [None, None]
+    counter = [0]
 
     class Slot(object):
         def __init__(self, tensor):
@@ -234,27 +238,40 @@ def main():
 
     host_spectra = np.empty((len(molecules), levels_local, n)) if args.host_output else None
 
+    def settle(which):
+        """Waits for the gather that last used buffer `which`."""
+        if pending[which] is not None:
+            pending[which].wait()
+            if not on_host:
+                torch.cuda.current_stream().synchronize()
+            pending[which] = None
+
     def step(count_evals=False):
+        which = counter[0] % len(spectra)
+        counter[0] += 1
+        settle(which)
         total = 0
         for m, handle in enumerate(handles):
             formula = molecules[m]
             result = engine.compute(handle, atmos.t[mine], atmos.p[mine], atmos.vmr[formula][mine],
                                     grid_v0, grid_vn, n_per_v, remove_pedestal=args.pedestal,
-                                    out=host_spectra[m] if args.host_output else Slot(spectra[m]),
+                                    out=host_spectra[m] if args.host_output
+                                    else Slot(spectra[which][m]),
                                     asynchronous=not args.host_output,
                                     want_evals=count_evals)
             if count_evals:
                 total += result[1]
         if world > 1:
-            # The engine runs on its own streams: finish the spectra, gather them, and let the
-            # collective finish before the next step may overwrite the send buffer.
+            # The engine runs on its own streams: finish the spectra, then start the gather;
+            # it completes while the next step computes into the other buffer.
             engine.synchronize()
-            dist.gather(spectra.cpu() if on_host else spectra, gathered, dst=0)
-            if not on_host:
-                torch.cuda.current_stream().synchronize()
+            source = spectra[which].cpu() if on_host else spectra[which]
+            pending[which] = dist.gather(source, gathered[which], dst=0, async_op=True)
         return total
 
     def fence():
+        settle(0)
+        settle(1)
         engine.synchronize()
         if world > 1:
             dist.barrier()
@@ -328,7 +345,8 @@ def main():
                             + (", far-field series on" if args.farfield else ""),
                 "lines": {t.formula: t.num_lines for t in tables},
                 "levels_total": levels_total, "atmosphere": args.profile, "parallelism": f"levels sharded over {world} GPU(s)"
-                + (f", {args.backend} gather to rank 0 inside the step" if world > 1 else ""),
+                + (f", {args.backend} gather to rank 0 every step (overlapping the next step)"
+                   if world > 1 else ""),
             },
             "evals_per_step": evals_per_step,
             "evals_per_s_per_gpu": value/world,
