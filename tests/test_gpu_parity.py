@@ -318,3 +318,21 @@ def test_empty_and_degenerate_inputs(engine, oracle):
             case = golden_io.Case("single", 0, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
             assert_spectrum(k, k_ref, case, f"single line {(v0, vn, npv, cut, ped)}", k_plain)
     engine.free(m)
+
+
+def test_very_wide_grid_pedestal_fallbacks(engine, oracle):
+    """A grid of 25 000 cm-1: the pedestal slots no longer fit LDS, so both chain kernels step
+    aside for the HBM-resident serial form (pedestal.h)."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("H2O", 1., 25000., num_lines=4000, seed=123,
+                                 tips_range=(150, 400))
+    molecule = engine.load(table)
+    v0, vn, npv = 1, 25001, 2
+    for ped in (True, False):
+        k = engine.compute(molecule, 260., 4.e4, 1e-3, v0, vn, npv, remove_pedestal=ped)[0]
+        k_ref, _ = oracle.absorption_port(table, 260., 4.e4, 1e-3, v0, vn, npv,
+                                          remove_pedestal=ped)
+        k_plain, _ = oracle.absorption_port(table, 260., 4.e4, 1e-3, v0, vn, npv)
+        case = golden_io.Case("wide", 0, 0, 0, 0, v0, vn, npv, 25, ped, None, 0)
+        assert_spectrum(k, k_ref, case, f"wide grid ped={ped}", k_plain)
+    engine.free(molecule)
