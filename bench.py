@@ -165,6 +165,40 @@ def profiled_traffic(workload):
     return None, None
 
 
+def _cpu_chunk(job):
+    """Worker of cpu_baseline_parallel: the C restatement on one sub-grid of the sample."""
+    from oracle import oracle
+    table, t, p, x, v0, vn, n_per_v, remove_pedestal = job
+    _, extras = oracle.absorption_port(table, t, p, x, v0, vn, n_per_v,
+                                       remove_pedestal=remove_pedestal)
+    return extras["evals"]
+
+
+def cpu_baseline_parallel(tables, atmos, v0, n_per_v, sample_cm, workers):
+    """What a user could do with multiprocessing around the reference's Gas: independent
+    (molecule, sub-grid) units of the same sample farmed out over `workers` processes
+    (our C restatement on arrays; pedestal off, the units would not be independent with it)."""
+    import multiprocessing
+    vn = v0 + int(sample_cm)
+    edges = np.linspace(v0, vn, workers + 1).astype(int)
+    jobs = []
+    for t in tables:
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi > lo:
+                near = t.subset((t.nu >= lo - 26.) & (t.nu <= hi + 26.))
+                jobs.append((near, atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], int(lo),
+                             int(hi), n_per_v, False))
+    context = multiprocessing.get_context("spawn")
+    with context.Pool(workers) as pool:
+        pool.map(_cpu_chunk, jobs[:workers])           # start-up and library load, untimed
+        start = time.perf_counter()
+        evals = sum(pool.map(_cpu_chunk, jobs, chunksize=1))
+        seconds = time.perf_counter() - start
+    return {"value": evals/seconds, "unit": "evals/s", "cores": workers, "kind": "port",
+            "sample": f"same sample as cpu_baseline cut into {len(jobs)} (molecule, sub-grid) "
+                      f"units, {evals:.4g} evals in {seconds:.2f} s"}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -385,6 +419,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, n_per_v,
                                                 args.cpu_sample_cm, args.pedestal)
+            workers = min(16, os.cpu_count() or 1)
+            if workers > 1:
+                line["cpu_baseline_parallel"] = cpu_baseline_parallel(
+                    tables, atmos, grid_v0, n_per_v, args.cpu_sample_cm, workers)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
