@@ -3,22 +3,26 @@
 // Reference statement: the row loop of pyLBL/c_lib/absorption.c:76-86 calling
 // spectra() -> voigt() (pyLBL/c_lib/voigt.c:21-25, :74-189), i.e. for every line a
 // read-modify-write sweep over its +-cut_off window of k[].  Here the loop nest is turned
-// inside out (a gather): one wavefront owns a tile of 64*P consecutive grid points, keeps
-// the P partial sums of each lane in registers, and walks the lines whose windows overlap
-// the tile.  k[] is written exactly once; the grid itself is never read (v[i] = v0 + i*dv
-// is formed in registers the way absorption.c:36-40 forms it).
+// inside out (a gather): a workgroup owns a tile of 64*P consecutive grid points, every lane
+// keeps P partial sums in registers, and the workgroup's four wavefronts walk the lines
+// whose windows overlap the tile (a quarter of them each).  k[] is written exactly once; the
+// grid itself is never read (v[i] = v0 + i*dv is formed in registers the way
+// absorption.c:36-40 forms it).
 //
 // Line scalars are wave-uniform, so they travel through the scalar unit (s_load into
 // SGPRs) rather than through vector registers or LDS: every VALU instruction of the inner
 // loop takes its line operand straight from an SGPR pair.
 //
 // Lines are kept sorted by wavenumber.  For a tile the schedule kernel (tile_schedule.h)
-// gives five cut points lo <= a1 <= c1 <= c2 <= a2 <= hi into that order:
-//   [a1,c1) and [c2,a2): windows certainly cover the whole tile and the tile is certainly
+// gives cut points lo <= a1 <= f1 <= c1 <= c2 <= f2 <= a2 <= hi into that order:
+//   [f1,c1) and [c2,f2): windows certainly cover the whole tile and the tile is certainly
 //                        in the Lorentz far wing of the line  -> branch-free fast loop,
-//                        four lines per reciprocal;
+//                        eight lines per reciprocal;
+//   [a1,f1) and [f2,a2): the same, and far enough away for the optional power series of
+//                        farfield.h (empty, f1 = a1 and f2 = a2, when that is off);
 //   [lo,a1), [c1,c2), [a2,hi): anything else -> per-line, per-64-point-row decisions
 //                        (window clipping, exact reference region chain near the core).
+// Work is handed out as WorkItems (a tile, or a share of a heavy tile's lines), heaviest first.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -120,7 +124,7 @@ struct AccumulateArgs
 };
 
 // Far-wing loop over two index ranges [a0,a1) and [b0,b1) whose lines all cover the whole
-// tile with the tile in their Lorentz wing.  Four lines share one reciprocal (lorentz_four);
+// tile with the tile in their Lorentz wing.  Eight (or four) lines share one reciprocal;
 // only whole groups of four are taken here, the caller sends the 0-3 left-over lines of each
 // range down the general path.  The records arrive by scalar loads whose latency is covered
 // by the other resident wavefronts of the SIMD.
