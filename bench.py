@@ -368,7 +368,7 @@ def main():
         evals_per_launch = evals_per_step_local/max(launches[2]/args.steps, 1)
         achieved = evals_per_launch*BYTES_PER_EVAL/(accumulate_ms*1e-3)/1e9
         line = {
-            "metric": "line x gridpoint Voigt evaluations per second (whole job)",
+            "metric": "line\u00d7gridpoint Voigt evals/sec (whole job; per GPU: evals_per_s_per_gpu; spectra/sec: spectra_per_s)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
