@@ -6,6 +6,8 @@ the constructor, and stays resident in HBM (the reference re-opens SQLite and re
 transition on every call, absorption.c:44-86); ``absorption_coefficients`` (plural) is the
 batched form over many levels that Spectroscopy uses.
 """
+import warnings
+
 import numpy as np
 
 from .engine import default_engine
@@ -55,6 +57,7 @@ class Gas(object):
             self.database = None
             table = lines_database
         self.num_lines = table.num_lines if table is not None else 0
+        self._first_nu = float(table.nu[0]) if self.num_lines else None
         if table is not None:
             self.molecule = self.engine.load(table)
 
@@ -87,6 +90,15 @@ class Gas(object):
         if self._deferred_error is not None:
             raise self._deferred_error
         v0, vn, n_per_v = grid_arguments(grid)
+        if range_policy == "reference" and self._first_nu is not None and \
+                self._first_nu < v0 - (cut_off + 1):
+            # pyLBL/c_lib/absorption.c:80-83 leaves its row loop at the first transition outside
+            # [v0-(cut_off+1), vn+cut_off+1]: with the first row below the grid that is every row.
+            warnings.warn(
+                f"{self.formula}: the first transition ({self._first_nu:g} cm-1) lies below "
+                f"v0-(cut_off+1) = {v0 - (cut_off + 1)} cm-1; like the reference this yields an "
+                "all-zero spectrum.  Pass range_policy='skip' to ignore out-of-range rows instead.",
+                RuntimeWarning, stacklevel=3)
         levels = np.atleast_1d(np.asarray(temperature, dtype=np.float64)).size
         if self.molecule is None:
             if out is not None:

@@ -47,6 +47,12 @@ def test_gas_over_database_file(small_database, oracle):
         k_ref, _ = oracle.absorption_port(tables["H2O"], 288.99, 98388., 6.637074e-3, v0, vn,
                                           npv, remove_pedestal=ped)
         check(k, k_ref, npv, ped, f"Gas H2O ped={ped}")
+    # The reference's range rule: first row below v0-26 -> zeros (absorption.c:80-83); the
+    # drop-in reproduces it and says so, range_policy="skip" is the way out.
+    high = np.arange(60., 90., 0.05)
+    with pytest.warns(RuntimeWarning, match="all-zero"):
+        assert not gas.absorption_coefficient(288.99, 98388., 6.6e-3, high).any()
+    assert gas.absorption_coefficient(288.99, 98388., 6.6e-3, high, range_policy="skip").any()
     # No TIPS rows: rc 0 and zeros in the reference (absorption.c:53-59).
     k = Gas(db, "N2O").absorption_coefficient(288.99, 98388., 3.2e-7, grid)
     assert k.shape == ((vn - v0)*npv,) and not k.any()
