@@ -152,6 +152,10 @@ class Spectroscopy(object):
         # n*k applied in the kernel epilogue, spectra left in HBM until the end.  Calls with a
         # pedestal overlap on the engine's lanes.
         pending = {}
+        # "total": the gases are added up on the device (LBL_ACCUMULATE), one copy back.
+        summed = None
+        sum_on_device = output_format not in ("all", "gas") and \
+            temperature.size*n*8 <= self.device_output_limit
         for name, mole_fraction in self.atmosphere.gases.items():
             data = self.cache.get(name)
             if data is None:
@@ -164,6 +168,15 @@ class Spectroscopy(object):
                                                      mole_fraction.ravel()[:1], self.grid)
                 continue
             engine = data.gas.engine
+            if sum_on_device:
+                first = summed is None
+                if first:
+                    summed = (engine, DeviceSpectra(engine, temperature.size, n))
+                data.gas.absorption_coefficients(
+                    temperature, pressure, mole_fraction.ravel(), self.grid,
+                    remove_pedestal=remove_pedestal, range_policy=range_policy,
+                    scale_density=True, out=summed[1], accumulate=not first, asynchronous=True)
+                continue
             out = None
             if temperature.size*n*8 <= self.device_output_limit:
                 out = DeviceSpectra(engine, temperature.size, n)
@@ -172,6 +185,14 @@ class Spectroscopy(object):
                 remove_pedestal=remove_pedestal, range_policy=range_policy,
                 scale_density=True, out=out, asynchronous=out is not None)
             pending[name] = (engine, result)
+        if sum_on_device:
+            total = np.zeros((temperature.size, self.grid.size))
+            if summed is not None:
+                summed[0].synchronize()
+                total = np.ascontiguousarray(summed[1].to_host()[:, :self.grid.size])
+                summed[1].free()
+            return self._create_output_dataset(
+                {"total": total.reshape(list(shape) + [self.grid.size])}, output_format)
         beta = {}
         for name in self.atmosphere.gases:
             varname = "{}_absorption".format(name)

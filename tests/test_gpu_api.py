@@ -94,6 +94,12 @@ def test_spectroscopy_lines_slot(small_database, oracle):
     np.testing.assert_allclose(np.asarray(total["absorption"]),
                                np.asarray(per_gas["H2O_absorption"]) +
                                np.asarray(per_gas["CO2_absorption"]), rtol=1e-14)
+    # Same with the pedestal removed (the default): the on-device sum goes through the
+    # un-pedestalled scratch buffer + pedestal_apply_kernel's accumulate form.
+    per_gas = spec.compute_absorption(output_format="gas")
+    total = spec.compute_absorption(output_format="total")
+    expect = np.asarray(per_gas["H2O_absorption"]) + np.asarray(per_gas["CO2_absorption"])
+    assert np.max(np.abs(np.asarray(total["absorption"]) - expect)) <= 1e-13*np.max(expect)
 
 
 def test_same_signature_c_entry(small_database, oracle):
