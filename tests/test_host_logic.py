@@ -152,3 +152,57 @@ def test_oracle_under_sanitizers(tmp_path):
                                  "PATH": "/usr/bin:/bin"})
     assert "clean" in result.stdout, result.stderr[-2000:]
     assert "runtime error" not in result.stderr and "AddressSanitizer" not in result.stderr
+
+
+class _Variable(object):
+    """The slice of an xarray DataArray that Atmosphere touches (xarray is not installed)."""
+    def __init__(self, data, standard_name):
+        self.data = np.asarray(data)
+        self.attrs = {"units": "1", "standard_name": standard_name}
+        self.dims = ("layer",)
+
+
+class _Dataset(object):
+    def __init__(self, data_vars):
+        self.data_vars = data_vars
+
+    def __getitem__(self, name):
+        return self.data_vars[name]
+
+
+def _dataset():
+    atmos = synthetic.fixture_atmosphere()
+    names = {"H2O": "water_vapor", "CO2": "carbon_dioxide", "O3": "ozone", "N2O": "nitrous_oxide",
+             "CO": "carbon_monoxide", "CH4": "methane", "O2": "oxygen", "N2": "nitrogen"}
+    data_vars = {"pressure": _Variable(atmos.p, "air_pressure"),
+                 "temperature": _Variable(atmos.t, "air_temperature")}
+    for formula, name in names.items():
+        data_vars[name] = _Variable(atmos.vmr[formula], f"mole_fraction_of_{name}_in_air")
+    return atmos, names, data_vars
+
+
+def test_atmosphere_from_dataset_like():
+    """Counterpart of the reference's tests/test_atmosphere.py: variables found by CF standard
+    name, or through a user mapping; a missing name is a ValueError."""
+    from pylbl_amd import Atmosphere
+    atmos, names, data_vars = _dataset()
+    for mapping in (None, {"play": "pressure", "tlay": "temperature", "mole_fraction": names}):
+        atm = Atmosphere(_Dataset(data_vars), mapping=mapping)
+        assert np.array_equal(atm.pressure, atmos.p) and np.array_equal(atm.temperature, atmos.t)
+        assert set(atm.gases) == set(names)
+        for formula in names:
+            assert np.array_equal(atm.gases[formula], atmos.vmr[formula])
+        assert atm.dims == ["layer"]
+    del data_vars["pressure"]
+    with pytest.raises(ValueError):
+        Atmosphere(_Dataset(data_vars))
+
+
+def test_atmosphere_from_plain_arrays():
+    from pylbl_amd import Atmosphere
+    atmos = synthetic.fixture_atmosphere()
+    for given in (atmos, {"p": atmos.p, "t": atmos.t, "vmr": atmos.vmr}):
+        atm = Atmosphere(given)
+        assert np.array_equal(atm.temperature, atmos.t) and set(atm.gases) == set(atmos.vmr)
+    with pytest.raises(ValueError):
+        Atmosphere({"p": atmos.p, "t": atmos.t, "vmr": {"H2O": atmos.vmr["H2O"][:2]}})
