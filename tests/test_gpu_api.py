@@ -332,3 +332,23 @@ def test_full_size_pedestal_properties(full_size):
     single = e.compute(handles["CO2"], atmos.t[2], atmos.p[2], atmos.vmr["CO2"][2], v0, vn, npv,
                        remove_pedestal=True)[0]
     assert np.array_equal(single, ped[2])
+
+
+def test_reference_known_answers_if_real_database_present():
+    """The reference's own known-answer test (tests/test_gas_optics.py:6-19) needs its
+    HITRAN-derived database ``pyLBL-2-7-23.db`` (anonymous FTP + secret directory), which does
+    not exist offline.  If a copy is pointed to by $PYLBL_DATABASE the same two numbers are
+    checked here with the reference's own tolerance."""
+    import os
+    path = os.environ.get("PYLBL_DATABASE")
+    if not path or not os.path.isfile(path):
+        pytest.skip("no real pyLBL database available ($PYLBL_DATABASE)")
+    from pylbl_amd import Gas
+    atmos = synthetic.fixture_atmosphere()
+    grid = np.arange(1., 3250., 0.1)
+    gas = Gas(Database(path), "H2O")
+    k = gas.absorption_coefficient(temperature=atmos.t[-1], pressure=atmos.p[-1],
+                                   volume_mixing_ratio=atmos.vmr["H2O"][-1], grid=grid)
+    k = k[:grid.size]
+    assert np.log(np.max(k)) == pytest.approx(-48.159224953962244)
+    assert np.log(np.sum(k)*(grid[1] - grid[0])) == pytest.approx(-46.496121930910135)
