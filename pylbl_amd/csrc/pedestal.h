@@ -570,7 +570,7 @@ constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at
 // spectrum on integer wavenumbers) and the per-window pedestal totals live in LDS; the
 // inputs of the next kChainChunk runs are staged cooperatively so that no global-memory
 // latency sits on the serial chain.
-template <bool USE_LDS>
+template <bool USE_LDS, bool WINDOW>
 __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ run_count,
                                                        int max_runs, int slot_stride,
                                                        GridSpec g, int n_cells, int n_bins,
@@ -628,6 +628,8 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
         fetch(0);
         park(stage_a, min(kChainChunk, count));
     }
+    int zone = 0;           // WINDOW: first slot held in registers
+    double window = 0.;     // WINDOW: slot zone + lane (all slots start at zero)
     for (int base = 0; base < count; base += kChainChunk)
     {
         const int chunk = min(kChainChunk, count - base);
@@ -657,6 +659,37 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
             const double vs = read_lane(mine.vs, r);
             const double dd = read_lane(mine.d, r);
             const bool bin_ok = bin >= 0 && bin < n_bins;
+            if (WINDOW)
+            {
+                // Register window: lane l holds slot zone + l.  A window is a contiguous
+                // range of at most 64 slots (the last grid point counts as slot n_cells), so
+                // consecutive windows almost always fit the zone already loaded and the step
+                // touches no memory on its dependent path: the end values come out of the
+                // registers with v_readlane, the update is one masked vector add.
+                if (first_slot < zone || last_slot > zone + 63)
+                {
+                    if (zone + lane <= n_cells) a[zone + lane] = window;
+                    if (USE_LDS) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+                    zone = first_slot;
+                    window = zone + lane <= n_cells ? a[zone + lane] : 0.;
+                }
+                const int f = first_slot - zone, e = last_slot - zone;
+                const bool interior = lane > f && lane < e;
+                const double add = interior ? staged[r*slot_stride + (lane - f)] : 0.;
+                const double a_s = read_lane(window, f);
+                const double a_e = read_lane(window, e);
+                const double delta_n = (a_s - a_e) + dd;
+                const double s_new = delta_n > 0. ? delta_n : 0.;
+                const double e_new = delta_n < 0. ? -delta_n : 0.;
+                const double pedestal = n_slots == 1 ? a_s + vs : (a_s + vs) - s_new;
+                double value = window + (add - pedestal);
+                if (!interior) value = window;
+                if (lane == e) value = e_new;
+                if (lane == f) value = n_slots == 1 ? 0. : s_new;
+                window = value;
+                if (lane == 0 && bin_ok) atomicAdd(&bins[bin], pedestal);
+                continue;
+            }
             // Everything the step reads is requested up front (one LDS round trip); the
             // interior slots do not depend on the end slots.
             const bool interior = lane > 0 && lane < n_slots - 1 && lane < 64;
@@ -711,6 +744,8 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
         }
         __syncthreads();
     }
+    if (WINDOW && zone + lane <= n_cells) a[zone + lane] = window;
+    __syncthreads();
     if (USE_LDS)
     {
         for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = bins[s];
@@ -849,11 +884,16 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
     {
         if (lds_bytes > 64*1024)
         {
-            check(hipFuncSetAttribute(reinterpret_cast<const void *>(run_chain_kernel<true>),
+            check(hipFuncSetAttribute(reinterpret_cast<const void *>(run_chain_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_bytes), "LDS opt-in");
+            check(hipFuncSetAttribute(reinterpret_cast<const void *>(run_chain_kernel<true, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_bytes), "LDS opt-in");
         }
-        hipLaunchKernelGGL(run_chain_kernel<true>, dim3(count), dim3(64), lds_bytes, stream,
+        // Windows of at most 64 slots (cut_off <= 30) keep the active slots in registers.
+        auto chain = slot_stride <= 64 ? run_chain_kernel<true, true> : run_chain_kernel<true, false>;
+        hipLaunchKernelGGL(chain, dim3(count), dim3(64), lds_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
                            ws.runs.data, ws.slot_sums.data, ws.regular.data, (double *)nullptr,
                            ws.bin_sum.data);
@@ -861,7 +901,8 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
     else
     {
         ws.slots.reserve((size_t)count*(n_cells + 1));
-        hipLaunchKernelGGL(run_chain_kernel<false>, dim3(count), dim3(64), staged_bytes, stream,
+        auto chain = slot_stride <= 64 ? run_chain_kernel<false, true> : run_chain_kernel<false, false>;
+        hipLaunchKernelGGL(chain, dim3(count), dim3(64), staged_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
                            ws.runs.data, ws.slot_sums.data, ws.regular.data, ws.slots.data,
                            ws.bin_sum.data);
