@@ -264,6 +264,7 @@ def main():
                      for _ in range(world)] for _ in range(2)]
     pending = [None, None]
     counter = [0]
+    use_all_gather = [False]
 
     class Slot(object):
         def __init__(self, tensor):
@@ -300,7 +301,15 @@ def main():
             # it completes while the next step computes into the other buffer.
             engine.synchronize()
             source = spectra[which].cpu() if on_host else spectra[which]
-            pending[which] = dist.gather(source, gathered[which], dst=0, async_op=True)
+            if not use_all_gather[0]:
+                try:
+                    pending[which] = dist.gather(source, gathered[which], dst=0, async_op=True)
+                except (RuntimeError, NotImplementedError, ValueError):
+                    use_all_gather[0] = True    # backend without gather: every rank collects
+            if use_all_gather[0]:
+                if gathered[which] is None:
+                    gathered[which] = [torch.empty_like(source) for _ in range(world)]
+                pending[which] = dist.all_gather(gathered[which], source, async_op=True)
         return total
 
     def fence():
