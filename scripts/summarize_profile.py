@@ -39,6 +39,11 @@ for name, c in summary["counters"].items():
         # reads are doubled before comparing with a byte count; WRITE_SIZE is exact.
         c["hbm_bytes_per_launch"] = 2*fetch + write
         c["hbm_bytes_per_launch_uncorrected"] = fetch + write
+for name, c in summary["counters"].items():
+    if "hbm_bytes_per_launch" in c and name in summary["kernels"]:
+        # Achieved HBM rate of the kernel against the 8 TB/s roofline (MI355X_MICROARCH.md).
+        c["hbm_gb_per_s"] = c["hbm_bytes_per_launch"]/(summary["kernels"][name]["avg_ms"]*1e-3)/1e9
+        c["hbm_fraction_of_8TBps"] = c["hbm_gb_per_s"]/8000.
 try:
     summary["bench_line"] = json.loads(open(f"{src}/bench_stats.json").read().strip().splitlines()[-1])
 except Exception as error:  # noqa
