@@ -133,6 +133,7 @@ struct Lane
     hipStream_t main = nullptr;     // prepare, schedule, accumulate, apply, copies
     hipStream_t side = nullptr;     // the pedestal pre-pass
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
+    hipEvent_t runs_found = nullptr;
     bool levels_in_flight = false;
     DeviceBuffer<LineWing> wing;
     DeviceBuffer<LineCore> core;
@@ -151,8 +152,13 @@ struct Lane
     void create()
     {
         HIP_TRY(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        // The pre-pass is short and latency-bound (a serial chain): its queue goes first
+        // whenever the accumulate grid frees a slot.
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
     }
@@ -168,6 +174,7 @@ struct Lane
         pinned_levels = nullptr;
         if (prepared != nullptr) (void)hipEventDestroy(prepared);
         if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
+        if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
         if (side != nullptr) (void)hipStreamDestroy(side);
@@ -209,7 +216,7 @@ struct lbl_engine
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
 
     // Timing.
-    struct Span { hipEvent_t begin, end; int kind; };
+    struct Span { hipEvent_t begin, end; int kind, counts; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     double time_ms[4] = {0., 0., 0., 0.};
@@ -229,14 +236,14 @@ struct lbl_engine
     }
 
     template <typename F>
-    void timed(int kind, hipStream_t on, F && launch)
+    void timed(int kind, hipStream_t on, F && launch, int counts = 1)
     {
         if (!timing)
         {
             launch();
             return;
         }
-        Span s{take_event(), take_event(), kind};
+        Span s{take_event(), take_event(), kind, counts};
         HIP_TRY(hipEventRecord(s.begin, on));
         launch();
         HIP_TRY(hipEventRecord(s.end, on));
@@ -252,7 +259,7 @@ struct lbl_engine
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s.begin, s.end));
             time_ms[s.kind] += ms;
-            launches[s.kind] += 1;
+            launches[s.kind] += s.counts;
             event_pool.push_back(s.begin);
             event_pool.push_back(s.end);
         }
@@ -659,9 +666,26 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
 
             if (!want_k) continue;
 
+            // The pedestal pre-pass only needs the per-line scalars: it runs on the side
+            // stream next to the accumulate kernel (its serial chain keeps one CU busy).
+            // Its run-finding kernels go first, beside schedule_kernel: once the accumulate
+            // grid owns the chip their wide workgroups would wait for it to drain.
+            hipStream_t ped_stream = engine->overlap_pedestal ? lane.side : stream;
             if (with_pedestal)
             {
-                HIP_TRY(hipEventRecord(lane.prepared, stream));
+                if (engine->overlap_pedestal)
+                {
+                    HIP_TRY(hipEventRecord(lane.prepared, stream));
+                    HIP_TRY(hipStreamWaitEvent(lane.side, lane.prepared, 0));
+                }
+                engine->timed(kTimePedestal, ped_stream, [&] {
+                    pedestal_find_runs(lane.pedestal, ped_stream, m->view(), lane.wing.data,
+                                       count);
+                }, 0);
+                if (engine->overlap_pedestal)
+                {
+                    HIP_TRY(hipEventRecord(lane.runs_found, lane.side));
+                }
             }
 
             // Tile cut points.
@@ -707,6 +731,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.accumulate = (!with_pedestal && out_device && add_into) ? 1 : 0;
             args.ablate = engine->ablate;
 
+            if (with_pedestal && engine->overlap_pedestal)
+            {
+                HIP_TRY(hipStreamWaitEvent(stream, lane.runs_found, 0));
+            }
             engine->timed(kTimeAccumulate, stream, [&] {
                 if (engine->farfield)
                 {
@@ -731,16 +759,9 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
 
             if (with_pedestal)
             {
-                // The pedestal pre-pass only needs the per-line scalars: it runs on the side
-                // stream next to the accumulate kernel (its serial chain keeps one CU busy).
-                hipStream_t ped_stream = engine->overlap_pedestal ? lane.side : stream;
-                if (engine->overlap_pedestal)
-                {
-                    HIP_TRY(hipStreamWaitEvent(lane.side, lane.prepared, 0));
-                }
                 engine->timed(kTimePedestal, ped_stream, [&] {
-                    pedestal_pass(lane.pedestal, ped_stream, m->view(), lane.wing.data,
-                                  lane.core.data, g, count, n_cells, engine->scan_chain != 0);
+                    pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
+                                    lane.core.data, g, count, n_cells, engine->scan_chain != 0);
                 });
                 if (engine->overlap_pedestal)
                 {

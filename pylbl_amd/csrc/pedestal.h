@@ -800,34 +800,34 @@ __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __re
     k[i] = value;
 }
 
-// Runs the whole pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are
-// already in HBM; leaves cell_sum / point_sum for the accumulate kernel's epilogue.
+// The pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are already in
+// HBM, in two halves (pedestal_find_runs, pedestal_finish) on the same stream.
 __global__ void fill_int_kernel(int * data, int n, int value)
 {
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if (i < n) data[i] = value;
 }
 
-inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
-                          const LineWing * wing, const LineCore * core, const GridSpec & g,
-                          int count, int n_cells, bool scan_chain = true)
+inline void pedestal_check(hipError_t status, const char * what)
 {
-    auto check = [](hipError_t status, const char * what) {
-        if (status != hipSuccess)
-        {
-            throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(status));
-        }
-    };
+    if (status != hipSuccess)
+    {
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(status));
+    }
+}
+
+// First half: finds the runs (three short scan kernels) and starts the copy of the run
+// counts to the host.  Their 1024-thread workgroups cannot be placed while an accumulate
+// grid fills the chip, so the engine orders them before the accumulate launch.
+inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
+                               const LineWing * wing, int count)
+{
+    auto check = pedestal_check;
     const long long n_lines = t.n_lines;
-    const int slot_stride = 2*g.cut_off + 3;
-    const int n_bins = n_cells + 2*g.cut_off + 3;
     const int n_blocks = (int)((n_lines + 1023)/1024);
     ws.block_count.reserve((size_t)count*n_blocks);
     ws.run_start.reserve((size_t)(count*n_lines));
     ws.run_count.reserve((size_t)count);
-    ws.bin_sum.reserve((size_t)count*n_bins);
-    ws.cell_sum.reserve((size_t)count*n_cells);
-    ws.point_sum.reserve((size_t)count*n_cells);
     hipLaunchKernelGGL(run_count_kernel, dim3(n_blocks, count), dim3(1024), 0, stream, wing,
                        t.sorted_of_row, n_lines, n_blocks, ws.block_count.data);
     hipLaunchKernelGGL(run_offset_kernel, dim3(count), dim3(1024), 0, stream, n_blocks,
@@ -839,6 +839,21 @@ inline void pedestal_pass(PedestalWorkspace & ws, hipStream_t stream, const Line
     ws.host_counts.resize((size_t)count);
     check(hipMemcpyAsync(ws.host_counts.data(), ws.run_count.data, count*sizeof(int),
                          hipMemcpyDeviceToHost, stream), "run count copy");
+}
+
+// Second half: waits for the run counts, then sums, links, chain and tables on `stream`;
+// leaves cell_sum / point_sum for pedestal_apply_kernel.
+inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
+                            const LineWing * wing, const LineCore * core, const GridSpec & g,
+                            int count, int n_cells, bool scan_chain = true)
+{
+    auto check = pedestal_check;
+    const long long n_lines = t.n_lines;
+    const int slot_stride = 2*g.cut_off + 3;
+    const int n_bins = n_cells + 2*g.cut_off + 3;
+    ws.bin_sum.reserve((size_t)count*n_bins);
+    ws.cell_sum.reserve((size_t)count*n_cells);
+    ws.point_sum.reserve((size_t)count*n_cells);
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
     for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
