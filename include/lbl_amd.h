@@ -117,6 +117,78 @@ int lbl_line_scalars(lbl_engine *engine, int32_t molecule, double temperature,
                      int32_t cut_off, int32_t remove_pedestal, int32_t range_policy,
                      double *derived);
 
+/* ---------------------------------------------------------------------------------------
+ * MT-CKD continua: mechanism slot 1 of Spectroscopy.compute_absorption
+ * (pyLBL/spectroscopy.py:193-197).  Replaces BandedContinuum.spectra
+ * (pyLBL/mt_ckd/utils.py:157-174) and the Continuum.spectra method of the 16 band classes
+ * (water_vapor.py, carbon_dioxide.py, nitrogen.py, oxygen.py, ozone.py).
+ * ------------------------------------------------------------------------------------- */
+
+/* Band formulas (the class each one replaces). */
+#define LBL_BAND_H2O_SELF        0  /* WaterVaporARMSelfContinuum      columns bs296, bs260          */
+#define LBL_BAND_H2O_FOREIGN     1  /* WaterVaporIASIForeignContinuum  columns bfh2o, scale          */
+#define LBL_BAND_CO2             2  /* CarbonDioxideHartmannContinuum  columns bfco2, chi, exponent  */
+#define LBL_BAND_N2_ROTATION     3  /* NitrogenCIAPureRotationContinuum ct_296, ct_220, sf_296, sf_220 */
+#define LBL_BAND_N2_FUNDAMENTAL  4  /* NitrogenCIAFundamentalContinuum xn2_272, xn2_228, a_h2o       */
+#define LBL_BAND_N2_OVERTONE     5  /* NitrogenCIAFirstOvertoneContinuum xn2                         */
+#define LBL_BAND_O2_FUNDAMENTAL  6  /* OxygenCIAFundamentalContinuum   o2_f, o2_t                    */
+#define LBL_BAND_O2_NIR          7  /* OxygenCIANIRContinuum           o2_inf1                       */
+#define LBL_BAND_O2_NIR2         8  /* OxygenCIANIR2Continuum          analytic shape / wavenumber   */
+#define LBL_BAND_O2_NIR3         9  /* OxygenCIANIR3Continuum          o2_inf3                       */
+#define LBL_BAND_O2_VISIBLE     10  /* OxygenVisibleContinuum          o2_invis                      */
+#define LBL_BAND_O2_HERZBERG    11  /* OxygenHerzbergContinuum         analytic shape                */
+#define LBL_BAND_O2_UV          12  /* OxygenUVContinuum               o2_infuv                      */
+#define LBL_BAND_O3_CHAPPUIS    13  /* OzoneChappuisWulfContinuum      x_o3, y_o3, z_o3              */
+#define LBL_BAND_O3_HARTLEY     14  /* OzoneHartleyHugginsContinuum    o3_hh0, o3_hh1, o3_hh2        */
+#define LBL_BAND_O3_UV          15  /* OzoneUVContinuum                o3_huv                        */
+#define LBL_MAX_BANDS            8
+
+/* One band: `size` coefficients per column on the grid lower_bound + j*resolution
+ * (utils.py:136-143); column[c] is the offset (in doubles) of column c in `table`, -1 if the
+ * formula has fewer columns. */
+typedef struct lbl_band
+{
+    int32_t kind;
+    int32_t size;
+    double lower_bound;
+    double resolution;
+    int64_t column[4];
+} lbl_band;
+
+/* Mole fractions a level supplies, in this order (the reference passes a dictionary of all
+ * gases, spectroscopy.py:173): the gas the continuum belongs to, H2O, O2, N2, and the sum
+ * over every gas of the atmosphere (air_number_density, utils.py:16-28). */
+#define LBL_VMR_SELF   0
+#define LBL_VMR_H2O    1
+#define LBL_VMR_O2     2
+#define LBL_VMR_N2     3
+#define LBL_VMR_TOTAL  4
+#define LBL_VMR_COUNT  5
+
+/* Uploads the bands of one continuum (<= LBL_MAX_BANDS) and their coefficient table. */
+int lbl_continuum_load(lbl_engine *engine, int32_t n_bands, const lbl_band *bands,
+                       const double *table, int64_t table_size, int32_t *continuum);
+int lbl_continuum_free(lbl_engine *engine, int32_t continuum);
+
+/* Uploads a spectral grid [cm-1] (any ascending array; the reference interpolates onto the
+ * caller's own array, utils.py:171-173) and keeps it in HBM. */
+int lbl_grid_load(lbl_engine *engine, int64_t n, const double *wavenumber, int32_t *grid);
+int lbl_grid_free(lbl_engine *engine, int32_t grid);
+
+/* Continuum extinction [m-1] at n_levels levels on a loaded grid: BandedContinuum.spectra.
+ *   pressure in Pa; vmr: n_levels rows of LBL_VMR_COUNT doubles;
+ *   extinction: n_levels rows of n doubles, row stride level_stride (0 = dense); host memory
+ *   unless LBL_OUT_DEVICE; LBL_ASYNC and LBL_ACCUMULATE as for lbl_compute. */
+int lbl_continuum_compute(lbl_engine *engine, int32_t continuum, int32_t grid,
+                          int32_t n_levels, const double *temperature, const double *pressure,
+                          const double *vmr, int32_t flags, double *extinction,
+                          int64_t level_stride);
+
+/* Coarse spectra [cm-1] of every band for one level, concatenated in band order:
+ * Continuum.spectra(temperature, pressure [mb], vmr) (utils.py:98-108). */
+int lbl_continuum_bands(lbl_engine *engine, int32_t continuum, double temperature,
+                        double pressure_mb, const double *vmr, double *spectra);
+
 /* Same signature and semantics as the reference's absorption() (absorption.c:19-30):
  * opens the SQLite file, uploads the molecule (cached per path+formula for the life of the
  * process), computes one level on device 0.  Returns 0 on success, 1 on error (message on

@@ -1,0 +1,261 @@
+// MT-CKD continua on the device: the counterpart of the reference's mechanism slot 1
+// (pyLBL/spectroscopy.py:193-197 -> BandedContinuum.spectra, pyLBL/mt_ckd/utils.py:157-174).
+//
+// A continuum is a short list of bands.  Each band has coefficient columns on its own
+// uniform coarse wavenumber grid and one formula (Continuum.spectra of the 16 classes in
+// water_vapor.py, carbon_dioxide.py, nitrogen.py, oxygen.py, ozone.py); the reference
+// evaluates the formula on the coarse grid, interpolates linearly to the user's grid with
+// numpy.interp (zero outside the band), multiplies by 100 (cm-1 -> m-1) and adds the bands up.
+//
+// Two kernels:
+//   band_spectra_kernel      thread = coarse point of one (level, band): a few hundred to a
+//                            few thousand points per band, negligible time;
+//   continuum_interp_kernel  thread = point of the user's grid for one level: reads the
+//                            wavenumber (8 B), looks the enclosing coarse interval of every
+//                            band up by arithmetic (the coarse grids are uniform), writes the
+//                            extinction (8 B).  HBM-bound: 16 B per point and level.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace lbl {
+
+// Band formulas.  The numbering is part of the C ABI (include/lbl_amd.h, LBL_BAND_*).
+enum BandKind : int
+{
+    kBandH2OSelf = 0,       // water_vapor.py:23-32     columns: bs296, bs260
+    kBandH2OForeign = 1,    // water_vapor.py:71-78     columns: bfh2o, scale
+    kBandCO2 = 2,           // carbon_dioxide.py:33-39  columns: bfco2, chi factor, T exponent
+    kBandN2Rotation = 3,    // nitrogen.py:19-30        columns: ct_296, ct_220, sf_296, sf_220
+    kBandN2Fundamental = 4, // nitrogen.py:40-54        columns: xn2_272, xn2_228, a_h2o
+    kBandN2Overtone = 5,    // nitrogen.py:63-68        columns: xn2
+    kBandO2Fundamental = 6, // oxygen.py:22-30          columns: o2_f, o2_t
+    kBandO2NIR = 7,         // oxygen.py:39-47          columns: o2_inf1
+    kBandO2NIR2 = 8,        // oxygen.py:69-74          columns: analytic shape / wavenumber
+    kBandO2NIR3 = 9,        // oxygen.py:90-94          columns: o2_inf3
+    kBandO2Visible = 10,    // oxygen.py:105-111        columns: o2_invis
+    kBandO2Herzberg = 11,   // oxygen.py:126-130        columns: analytic shape
+    kBandO2UV = 12,         // oxygen.py:138-141        columns: o2_infuv
+    kBandO3Chappuis = 13,   // ozone.py:23-28           columns: x_o3, y_o3, z_o3
+    kBandO3Hartley = 14,    // ozone.py:46-52           columns: o3_hh0, o3_hh1, o3_hh2
+    kBandO3UV = 15,         // ozone.py:68-71           columns: o3_huv
+    kBandKinds = 16
+};
+
+constexpr int kMaxBands = 8;
+
+struct Band
+{
+    int kind;
+    int size;               // coarse points
+    double lower;           // coarse wavenumber j = lower + j*resolution (utils.py:142-143)
+    double resolution;
+    long long column[4];    // offsets of the coefficient columns in the table, -1 = unused
+    long long spectrum;     // offset of this band's coarse spectrum in a level's workspace
+};
+
+struct BandSet
+{
+    int n_bands;
+    int coarse_points;      // sum of sizes = workspace doubles per level
+    Band band[kMaxBands];
+};
+
+// What the formulas need from a level (utils.py:16-42 evaluated on the host).
+struct ContinuumLevel
+{
+    double t;               // [K]
+    double p;               // [mb]
+    double dry;             // dry-air number density [cm-3]
+    double air;             // air number density [cm-3]
+    double self;            // mole fraction of the gas the continuum belongs to
+    double h2o, o2, n2;     // mole fractions the formulas refer to by name
+};
+
+namespace mtckd {
+constexpr double kLoschmidt = 2.6867775e19;     // utils.py:7
+constexpr double kP0 = 1013.25;                 // utils.py:8
+constexpr double kC2 = 1.4387752;               // utils.py:9
+constexpr double kT0 = 296.;                    // utils.py:10
+constexpr double kT273 = 273.15;                // utils.py:11
+}
+
+// utils.py:45-59.  Its x <= 0.01 branch is always overwritten by the x <= 10 one.
+__device__ __forceinline__ double radiation_term(double w, double t)
+{
+    const double x = w/(t/mtckd::kC2);
+    if (x <= 10.)
+    {
+        const double e = exp(-x);
+        return w*(1. - e)/(1. + e);
+    }
+    return w;
+}
+
+// Continuum.spectra of one band at coarse point j [cm-1].
+__device__ inline double band_value(const Band & b, const double * __restrict__ table,
+                                    const ContinuumLevel & s, int j)
+{
+    using namespace mtckd;
+    const double w = b.lower + (double)j*b.resolution;
+    const double rad = radiation_term(w, s.t);
+    const double * c0 = table + b.column[0];
+    const double * c1 = table + b.column[1];
+    const double * c2 = table + b.column[2];
+    const double * c3 = table + b.column[3];
+    switch (b.kind)
+    {
+    case kBandH2OSelf:
+    {
+        const double n = s.dry*s.h2o;
+        return n*(n/s.air)*(s.p/kP0)*(kT0/s.t)*1.e-20*rad*
+               c0[j]*pow(c1[j]/c0[j], (s.t - kT0)/(260. - kT0));
+    }
+    case kBandH2OForeign:
+    {
+        const double n = s.dry*s.h2o;
+        return (1. - (n/s.air))*(s.p/kP0)*(kT0/s.t)*1.e-20*n*rad*c1[j]*c0[j];
+    }
+    case kBandCO2:
+    {
+        const double n = s.dry*s.self;
+        return n*1.e-20*(s.p/kP0)*(kT0/s.t)*rad*c1[j]*pow(s.t/246., c2[j])*c0[j];
+    }
+    case kBandN2Rotation:
+    {
+        const double tau = (s.dry*s.n2/kLoschmidt)*(s.p/kP0)*(kT273/s.t);
+        const double f = (s.t - kT0)/(220. - kT0);
+        const double c = c0[j]*pow(c1[j]/c0[j], f);
+        const double sf = c2[j]*pow(c3[j]/c2[j], f);
+        const double fo2 = (sf - 1.)*s.n2/s.o2;
+        return tau*rad*c*(s.n2 + fo2*s.o2 + s.h2o);
+    }
+    case kBandN2Fundamental:
+    {
+        const double tau = (s.dry*s.n2/kLoschmidt)*(s.p/kP0)*(kT273/s.t);
+        const double xt = (1./s.t - 1./272.)/(1./228. - 1./272.);
+        double c = 0.;
+        if (j > 0 && j < b.size - 1) c = c0[j]*pow(c1[j]/c0[j], xt);
+        c = c/w;
+        const double with_o2 = (1.294 - 0.4545*s.t/kT0)*c;
+        const double with_h2o = (9./7.)*c2[j]*c;
+        return tau*rad*(c*s.n2 + s.o2*with_o2 + s.h2o*with_h2o);
+    }
+    case kBandN2Overtone:
+    {
+        const double tau = (s.dry*s.n2/kLoschmidt)*(s.p/kP0)*(kT273/s.t)*(s.n2 + s.o2 + s.h2o);
+        return tau*rad*c0[j]/w;
+    }
+    case kBandO2Fundamental:
+    {
+        const double tau = s.dry*s.o2*1.e-20*(s.p/kP0)*(kT273/s.t);
+        return tau*rad*(1.e20/kLoschmidt)*c0[j]*exp(c1[j]*((1./kT0) - (1./s.t)))/w;
+    }
+    case kBandO2NIR:
+    {
+        const double tau = (s.dry*s.o2/kLoschmidt)*(s.p/kP0)*(kT273/s.t)*
+                           ((1./0.446)*s.o2 + (0.3/0.446)*s.n2 + s.h2o);
+        return tau*rad*c0[j]/w;
+    }
+    case kBandO2NIR2:
+    {
+        const double n = s.dry*s.o2;
+        const double adj = (n/s.air)*(1./s.o2)*n*1.e-20*(s.p/kP0)*(kT0/s.t);
+        return adj*rad*c0[j];
+    }
+    case kBandO2NIR3:
+        return (s.dry*s.o2/kLoschmidt)*(s.p/kP0)*(kT273/s.t)*rad*c0[j]/w;
+    case kBandO2Visible:
+    {
+        const double n = s.dry*s.o2;
+        const double adj = (n/s.air)*n*1.e-20*(s.p/kP0)*(kT273/s.t);
+        const double factor = 1./(kLoschmidt*1.e-20*(55.*kT273/kT0)*(55.*kT273/kT0)*89.5);
+        return adj*rad*factor*c0[j]/w;
+    }
+    case kBandO2Herzberg:
+        return 1.e-20*(s.dry*s.o2)*rad*(1. + 0.83*(s.p/kP0)*(kT273/s.t))*c0[j]/w;
+    case kBandO2UV:
+        return 1.e-20*(s.dry*s.o2)*rad*c0[j]/w;
+    case kBandO3Chappuis:
+    {
+        const double dt = s.t - kT273;
+        return 1.e-20*(s.dry*s.self)*rad*(c0[j] + c1[j]*dt + c2[j]*dt*dt)/w;
+    }
+    case kBandO3Hartley:
+    {
+        const double dt = s.t - kT273;
+        return 1.e-20*(s.dry*s.self)*rad*(c0[j]/w)*(1. + c1[j]*dt + c2[j]*dt*dt);
+    }
+    case kBandO3UV:
+        return (s.dry*s.self)*rad*c0[j]/w;
+    default:
+        return 0.;
+    }
+}
+
+// grid = (coarse points of the widest band / 256, bands, levels).
+__global__ __launch_bounds__(256) void band_spectra_kernel(BandSet set,
+                                                           const double * __restrict__ table,
+                                                           const ContinuumLevel * __restrict__ levels,
+                                                           double * __restrict__ coarse)
+{
+    const Band & b = set.band[blockIdx.y];
+    const int j = blockIdx.x*256 + threadIdx.x;
+    if (j >= b.size) return;
+    const ContinuumLevel s = levels[blockIdx.z];
+    coarse[(long long)blockIdx.z*set.coarse_points + b.spectrum + j] = band_value(b, table, s, j);
+}
+
+// numpy.interp(x, xp, fp, left=0, right=0) for one band with xp[j] = lower + j*resolution
+// (numpy/core/src/multiarray/compiled_base.c, arr_interp: interval by search, then
+// slope*(x - xp[j]) + fp[j], fp[j] itself on a knot, the same fallbacks for a NaN result).
+__device__ __forceinline__ double band_interp(const Band & b, const double * __restrict__ fp,
+                                              double x)
+{
+    const int last = b.size - 1;
+    const double x_first = b.lower;
+    const double x_last = b.lower + (double)last*b.resolution;
+    if (!(x >= x_first) || !(x <= x_last)) return 0.;     // also drops a NaN wavenumber
+    int j = (int)((x - b.lower)/b.resolution);
+    j = j < 0 ? 0 : (j > last ? last : j);
+    // Largest j with xp[j] <= x, whatever the rounding of the quotient did.
+    while (j < last && b.lower + (double)(j + 1)*b.resolution <= x) ++j;
+    while (j > 0 && b.lower + (double)j*b.resolution > x) --j;
+    const double xj = b.lower + (double)j*b.resolution;
+    const double fj = fp[j];
+    if (j == last || xj == x) return fj;
+    const double xn = b.lower + (double)(j + 1)*b.resolution;
+    const double fn = fp[j + 1];
+    const double slope = (fn - fj)/(xn - xj);
+    double value = slope*(x - xj) + fj;
+    if (value != value)
+    {
+        value = slope*(x - xn) + fn;
+        if (value != value && fj == fn) value = fj;
+    }
+    return value;
+}
+
+// grid = (points / 256, levels).  extinction[level][i] (+)= 100 * sum over bands.
+__global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
+                                                               const double * __restrict__ coarse,
+                                                               const double * __restrict__ wavenumber,
+                                                               long long n, double * __restrict__ out,
+                                                               long long level_stride, int accumulate)
+{
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = wavenumber[i];
+    const double * spectra = coarse + (long long)blockIdx.y*set.coarse_points;
+    double total = 0.;
+    for (int k = 0; k < set.n_bands; ++k)
+    {
+        const Band & b = set.band[k];
+        total += band_interp(b, spectra + b.spectrum, x)*100.;      // utils.py:171-173
+    }
+    double * target = out + (long long)blockIdx.y*level_stride + i;
+    if (accumulate) total += *target;
+    *target = total;
+}
+
+}  // namespace lbl

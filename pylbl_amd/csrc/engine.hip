@@ -21,6 +21,7 @@
 
 #include "../../include/lbl_amd.h"
 #include "accumulate.h"
+#include "continuum.h"
 #include "farfield.h"
 #include "line_prep.h"
 #include "pedestal.h"
@@ -193,6 +194,56 @@ struct Lane
 
 constexpr int kLanes = 8;
 
+// One continuum (continuum.h): its bands, their coefficient table and the per-level
+// workspace of coarse spectra.
+struct ContinuumSet
+{
+    BandSet set;
+    DeviceBuffer<double> table;
+    DeviceBuffer<ContinuumLevel> levels;
+    DeviceBuffer<double> coarse;        // [levels][set.coarse_points]
+    DeviceBuffer<double> staging;       // extinction on its way to host memory
+    int widest = 0;                     // points of the largest band
+    // Level scalars go through a pinned block; `done` marks the last kernel that reads it
+    // and the coarse spectra, so that a later call waits for that only.
+    ContinuumLevel * pinned = nullptr;
+    size_t pinned_capacity = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+
+    void wait()
+    {
+        if (in_flight) HIP_TRY(hipEventSynchronize(done));
+        in_flight = false;
+    }
+    void mark(hipStream_t stream)
+    {
+        if (done == nullptr) HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done, stream));
+        in_flight = true;
+    }
+    void reserve_pinned(size_t count)
+    {
+        if (count <= pinned_capacity) return;
+        if (pinned != nullptr) (void)hipHostFree(pinned);
+        pinned = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), count*sizeof(ContinuumLevel),
+                              hipHostMallocDefault));
+        pinned_capacity = count;
+    }
+    ~ContinuumSet()
+    {
+        if (done != nullptr) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); }
+        if (pinned != nullptr) (void)hipHostFree(pinned);
+    }
+};
+
+struct SpectralGrid
+{
+    long long n = 0;
+    DeviceBuffer<double> wavenumber;
+};
+
 }  // namespace
 
 struct lbl_engine
@@ -201,6 +252,8 @@ struct lbl_engine
     hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
     std::string error;
     std::vector<std::unique_ptr<Molecule>> molecules;
+    std::vector<std::unique_ptr<ContinuumSet>> continua;
+    std::vector<std::unique_ptr<SpectralGrid>> grids;
     Lane lanes[kLanes];
     unsigned next_lane = 0;
 
@@ -908,6 +961,8 @@ int lbl_engine_destroy(lbl_engine * engine)
     }
     for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
     engine->molecules.clear();
+    engine->continua.clear();
+    engine->grids.clear();
     for (auto & lane : engine->lanes) lane.destroy();
     delete engine;
     return LBL_OK;
@@ -1181,4 +1236,5 @@ int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int6
 
 }  // extern "C"
 
+#include "continuum_entry.inc"
 #include "sqlite_entry.inc"

@@ -4,7 +4,8 @@ This is the only Python<->native boundary of the package, the counterpart of
 pyLBL/c_lib/gas_optics.py:11-26,68-91 in the reference.  There is no CPU fallback: if the
 library is missing or no MI355X is visible, creating an Engine raises.
 """
-from ctypes import CDLL, POINTER, byref, c_char_p, c_double, c_int32, c_int64, c_void_p
+from ctypes import CDLL, POINTER, Structure, byref, c_char_p, c_double, c_int32, c_int64, \
+                   c_void_p
 from pathlib import Path
 
 import numpy as np
@@ -25,7 +26,18 @@ EXPORTED_SYMBOLS = (
     "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_line_scalars", "lbl_absorption", "lbl_version",
+    "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
+    "lbl_continuum_compute", "lbl_continuum_bands",
 )
+
+VMR_SELF, VMR_H2O, VMR_O2, VMR_N2, VMR_TOTAL, VMR_COUNT = 0, 1, 2, 3, 4, 5
+MAX_BANDS = 8
+
+
+class BandDescriptor(Structure):
+    """struct lbl_band of include/lbl_amd.h."""
+    _fields_ = [("kind", c_int32), ("size", c_int32), ("lower_bound", c_double),
+                ("resolution", c_double), ("column", c_int64*4)]
 
 _library = None
 
@@ -67,6 +79,15 @@ def library():
     lib.lbl_absorption.argtypes = [c_double]*3 + [c_int32]*3 + [c_void_p, c_char_p, c_char_p,
                                   c_int32, c_int32]
     lib.lbl_version.restype = c_char_p
+    lib.lbl_continuum_load.argtypes = [c_void_p, c_int32, POINTER(BandDescriptor), c_void_p,
+                                       c_int64, i32p]
+    lib.lbl_continuum_free.argtypes = [c_void_p, c_int32]
+    lib.lbl_grid_load.argtypes = [c_void_p, c_int64, c_void_p, i32p]
+    lib.lbl_grid_free.argtypes = [c_void_p, c_int32]
+    lib.lbl_continuum_compute.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_void_p, c_int64]
+    lib.lbl_continuum_bands.argtypes = [c_void_p, c_int32, c_double, c_double, c_void_p,
+                                        c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("lbl_last_error", "lbl_stream", "lbl_version"):
             getattr(lib, name).restype = c_int32
@@ -199,6 +220,83 @@ class Engine(object):
 
     def synchronize(self):
         self._check(self.lib.lbl_synchronize(self.handle))
+
+    # -- continua (slot 1) -----------------------------------------------------------------
+    def load_continuum(self, bands):
+        """Uploads a list of bands, each (kind, lower_bound, resolution, [columns]); returns
+        the continuum handle."""
+        if not 1 <= len(bands) <= MAX_BANDS:
+            raise ValueError(f"a continuum has 1 to {MAX_BANDS} bands.")
+        descriptors = (BandDescriptor*len(bands))()
+        pieces, offset = [], 0
+        for d, (kind, lower, resolution, columns) in zip(descriptors, bands):
+            columns = [_f64(c) for c in columns]
+            size = columns[0].size
+            if any(c.shape != (size,) for c in columns) or len(columns) > 4:
+                raise ValueError("the columns of a band must be 1-d and equally long (<= 4).")
+            d.kind, d.size, d.lower_bound, d.resolution = int(kind), size, float(lower), \
+                float(resolution)
+            for i in range(4):
+                d.column[i] = -1
+            for i, c in enumerate(columns):
+                d.column[i] = offset
+                offset += size
+                pieces.append(c)
+        table = _f64(np.concatenate(pieces))
+        handle = c_int32(-1)
+        self._check(self.lib.lbl_continuum_load(self.handle, len(bands), descriptors,
+                                                table.ctypes.data, table.size, byref(handle)))
+        return handle.value
+
+    def free_continuum(self, continuum):
+        self._check(self.lib.lbl_continuum_free(self.handle, int(continuum)))
+
+    def load_grid(self, wavenumber):
+        """Uploads a spectral grid [cm-1]; returns the grid handle."""
+        grid = _f64(wavenumber)
+        if grid.ndim != 1 or grid.size < 1:
+            raise ValueError("the grid must be a non-empty 1-d array.")
+        handle = c_int32(-1)
+        self._check(self.lib.lbl_grid_load(self.handle, grid.size, grid.ctypes.data,
+                                           byref(handle)))
+        return handle.value
+
+    def free_grid(self, grid):
+        self._check(self.lib.lbl_grid_free(self.handle, int(grid)))
+
+    def continuum_compute(self, continuum, grid, n, temperature, pressure, vmr, out=None,
+                          accumulate=False, asynchronous=False):
+        """Continuum extinction [m-1]: float64[levels, n] (or fills `out`, host array or
+        DeviceSpectra).  vmr is [levels, VMR_COUNT]; pressure in Pa."""
+        t, p = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure))
+        x = _f64(vmr).reshape(-1, VMR_COUNT)
+        if not (t.ndim == 1 and t.shape == p.shape and x.shape[0] == t.size):
+            raise ValueError("temperature, pressure [levels] and vmr [levels, 5] disagree.")
+        flags = (ACCUMULATE if accumulate else 0) | (ASYNC if asynchronous else 0)
+        if out is None:
+            out = np.zeros((t.size, n), dtype=np.float64)
+        # Rows may be longer than the grid (the lines path pads them to whole wavenumbers).
+        if len(out.shape) != 2 or out.shape[0] != t.size or out.shape[1] < n:
+            raise ValueError(f"out has shape {out.shape}, need ({t.size}, >= {n}).")
+        if hasattr(out, "pointer"):
+            pointer, flags = out.pointer, flags | OUT_DEVICE
+        else:
+            if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be C-contiguous float64[levels, >= n].")
+            pointer = c_void_p(out.ctypes.data)
+        self._check(self.lib.lbl_continuum_compute(
+            self.handle, int(continuum), int(grid), t.size, t.ctypes.data, p.ctypes.data,
+            x.ctypes.data, flags, pointer, int(out.shape[1])))
+        return out
+
+    def continuum_bands(self, continuum, sizes, temperature, pressure_mb, vmr):
+        """Coarse spectra [cm-1] of each band for one level (list of arrays)."""
+        x = _f64(vmr).reshape(VMR_COUNT)
+        spectra = np.zeros(int(sum(sizes)), dtype=np.float64)
+        self._check(self.lib.lbl_continuum_bands(self.handle, int(continuum), float(temperature),
+                                                 float(pressure_mb), x.ctypes.data,
+                                                 spectra.ctypes.data))
+        return np.split(spectra, np.cumsum(sizes)[:-1])
 
     def timing(self, reset=False):
         """(milliseconds[4], launches[4]) for prepare, schedule, accumulate, pedestal."""

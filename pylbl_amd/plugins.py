@@ -8,10 +8,13 @@ inserting itself, which is what ``register`` does (also into pyLBL's own diction
 that package is importable).
 """
 from .gas_optics import Gas
+from .mt_ckd import CONTINUA
 
 molecular_lines = {"mi355x": Gas}
 cross_sections = {}
-continua = {}
+# Continua: model name -> {"CO2": class, "H2OForeign": class, ...} (plugins.py:24-34).  The
+# MT-CKD model keeps the reference's name, so Spectroscopy's default fills slot 1.
+continua = {"mt_ckd": CONTINUA}
 models = molecular_lines.keys()
 
 

@@ -1,7 +1,6 @@
-"""Host orchestration of the lines slot: the counterpart of
-``Spectroscopy.compute_absorption`` (pyLBL/spectroscopy.py:144-206) restricted to mechanism
-slot 0 ("lines"); continua (slot 1) and cross-sections (slot 2) are outside this build's
-scope and stay zero.
+"""Host orchestration: the counterpart of ``Spectroscopy.compute_absorption``
+(pyLBL/spectroscopy.py:144-206) for mechanism slots 0 ("lines") and 1 ("continuum", MT-CKD);
+cross-sections (slot 2) are outside this build's scope and stay zero.
 
 What is kept from the reference: constructor keywords and the KeyError for an unknown
 backend name (:88-118); molecule-outer / level-inner semantics with no state carried between
@@ -87,35 +86,62 @@ class Atmosphere(object):
 
 
 class MoleculeCache(object):
-    """Caches the per-molecule backend object (pyLBL/spectroscopy.py:32-69); building it
-    uploads the molecule's line table to HBM once."""
-    def __init__(self, name, lines_database, lines_engine, device):
+    """Caches the per-molecule backend objects (pyLBL/spectroscopy.py:32-69): building them
+    uploads the molecule's line table and continuum coefficients to HBM once."""
+    def __init__(self, name, lines_database, lines_engine, continua_engine, device):
         try:
             self.gas = lines_engine(lines_database, name, device=device)
         except (AliasNotFoundError, IsotopologuesNotFoundError,
                 TipsDataNotFoundError, TransitionsNotFoundError):
             self.gas = None
+        # Water vapour has two continua, every other gas at most one (spectroscopy.py:58-65).
+        names = [name + "Foreign", name + "Self"] if name == "H2O" else [name]
+        self.gas_continua = None
+        if continua_engine is not None:
+            try:
+                self.gas_continua = [continua_engine[x](device=device) for x in names]
+            except KeyError:
+                self.gas_continua = None
+
+
+class _Sum(object):
+    """A [levels, n] block in HBM that kernels write first and add into afterwards."""
+    def __init__(self, engine, levels, n):
+        self.engine = engine
+        self.buffer = DeviceSpectra(engine, levels, n)
+        self.written = False
+
+    def take(self):
+        """True if the next kernel must add to what is there."""
+        written, self.written = self.written, True
+        return written
+
+    def to_host(self, columns):
+        values = np.ascontiguousarray(self.buffer.to_host()[:, :columns])
+        self.buffer.free()
+        return values
 
 
 class Spectroscopy(object):
-    """Line-by-line gas optics (lines mechanism) on an MI355X.
+    """Line-by-line gas optics (lines and MT-CKD continuum mechanisms) on an MI355X.
 
     Attributes mirror pyLBL/spectroscopy.py:72-86.
     """
     def __init__(self, atmosphere, grid, database, mapping=None, lines_backend="mi355x",
                  continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0):
         self.atmosphere = Atmosphere(atmosphere, mapping=mapping)
-        self.grid = np.asarray(grid, dtype=np.float64)
+        self.grid = np.ascontiguousarray(grid, dtype=np.float64)
         self.lines_database = database
         self.lines_backend = lines_backend
         self.lines_engine = molecular_lines[lines_backend]      # KeyError if unknown
         self.continua_backend = continua_backend
-        self.continua_engine = continua.get(continua_backend)   # not built: slot 1 stays 0
+        # None switches the mechanism off; an unknown name is a KeyError (spectroscopy.py:118).
+        self.continua_engine = None if continua_backend is None else continua[continua_backend]
         self.cross_sections_backend = cross_sections_backend
-        self.cross_sections_engine = cross_sections.get(cross_sections_backend)
+        self.cross_sections_engine = cross_sections.get(cross_sections_backend)  # not built
         self.cache = {}
         self.device = device
-        self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per molecule
+        self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
         dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
@@ -125,10 +151,18 @@ class Spectroscopy(object):
     def list_molecules(self):
         return self.lines_database.molecules()
 
+    def _molecule(self, name):
+        data = self.cache.get(name)
+        if data is None:
+            data = MoleculeCache(name, self.lines_database, self.lines_engine,
+                                 self.continua_engine, self.device)
+            self.cache[name] = data
+        return data
+
     def compute_absorption(self, output_format="all", remove_pedestal=None,
                            range_policy="reference"):
-        """Computes the lines absorption coefficient [m-1] on the grid for every level and
-        gas of the atmosphere.
+        """Computes the absorption coefficient [m-1] on the grid for every level and gas of
+        the atmosphere: spectral lines (slot 0) and MT-CKD continua (slot 1).
 
         Args:
             output_format: "all" (per gas, per mechanism), "gas" (per gas, mechanisms summed)
@@ -143,75 +177,105 @@ class Spectroscopy(object):
         """
         temperature = self.atmosphere.temperature.ravel()
         pressure = self.atmosphere.pressure.ravel()
-        shape = self.atmosphere.temperature.shape
+        shape = list(self.atmosphere.temperature.shape)
+        levels = temperature.size
         if remove_pedestal is None:
             remove_pedestal = self.continua_backend == "mt_ckd"
         v0, vn, n_per_v = grid_arguments(self.grid)
         n = (vn - v0)*n_per_v
-        # Queue every molecule before waiting: one batched call per molecule for all levels,
-        # n*k applied in the kernel epilogue, spectra left in HBM until the end.  Calls with a
-        # pedestal overlap on the engine's lanes.
-        pending = {}
-        # "total": the gases are added up on the device (LBL_ACCUMULATE), one copy back.
-        summed = None
-        sum_on_device = output_format not in ("all", "gas") and \
-            temperature.size*n*8 <= self.device_output_limit
-        for name, mole_fraction in self.atmosphere.gases.items():
-            data = self.cache.get(name)
-            if data is None:
-                data = MoleculeCache(name, self.lines_database, self.lines_engine, self.device)
-                self.cache[name] = data
-            if data.gas is None or data.gas.molecule is None:
-                if data.gas is not None:
-                    # Deferred errors (unknown alias) surface here like in the reference.
-                    data.gas.absorption_coefficients(temperature[:1], pressure[:1],
-                                                     mole_fraction.ravel()[:1], self.grid)
+        columns = self.grid.size
+        mode = output_format if output_format in ("all", "gas") else "total"
+        # Every gas at every level, the dictionary the continua read (spectroscopy.py:173).
+        mole_fractions = {name: x.ravel() for name, x in self.atmosphere.gases.items()}
+        in_hbm = levels*n*8 <= self.device_output_limit
+        engine = None
+
+        # Queue every kernel before waiting: one batched call per (molecule, mechanism) for
+        # all levels, n*k applied in the kernel epilogue, spectra left in HBM until the end;
+        # the sums over mechanisms ("gas") and over gases ("total") happen on the device.
+        blocks = {}             # (gas, mechanism) -> _Sum or host array
+        total = None
+        for name in self.atmosphere.gases:
+            data = self._molecule(name)
+            gas = data.gas
+            if gas is not None and gas.molecule is None:
+                # Deferred errors (unknown alias) surface here like in the reference.
+                gas.absorption_coefficients(temperature[:1], pressure[:1],
+                                            mole_fractions[name][:1], self.grid)
+                gas = None
+            continua_here = data.gas_continua or []
+            if gas is None and not continua_here:
                 continue
-            engine = data.gas.engine
-            if sum_on_device:
-                first = summed is None
-                if first:
-                    summed = (engine, DeviceSpectra(engine, temperature.size, n))
-                data.gas.absorption_coefficients(
-                    temperature, pressure, mole_fraction.ravel(), self.grid,
+            if engine is None:
+                engine = gas.engine if gas is not None else continua_here[0].engine
+            if not in_hbm:
+                # Too large to keep: one host block per mechanism, summed by numpy below.
+                if gas is not None:
+                    blocks[(name, 0)] = gas.absorption_coefficients(
+                        temperature, pressure, mole_fractions[name], self.grid,
+                        remove_pedestal=remove_pedestal, range_policy=range_policy,
+                        scale_density=True)[:, :columns]
+                for continuum in continua_here:
+                    values = continuum.spectra_levels(temperature, pressure, mole_fractions,
+                                                      self.grid)
+                    blocks[(name, 1)] = blocks[(name, 1)] + values if (name, 1) in blocks \
+                        else values
+                continue
+            if mode == "total":
+                if total is None:
+                    total = _Sum(engine, levels, n)
+                lines_sum = continuum_sum = total
+            elif mode == "gas":
+                lines_sum = continuum_sum = blocks[(name, 0)] = _Sum(engine, levels, n)
+            else:
+                lines_sum = blocks[(name, 0)] = _Sum(engine, levels, n) if gas is not None \
+                    else None
+                continuum_sum = blocks[(name, 1)] = _Sum(engine, levels, n) if continua_here \
+                    else None
+            if gas is not None:
+                gas.absorption_coefficients(
+                    temperature, pressure, mole_fractions[name], self.grid,
                     remove_pedestal=remove_pedestal, range_policy=range_policy,
-                    scale_density=True, out=summed[1], accumulate=not first, asynchronous=True)
-                continue
-            out = None
-            if temperature.size*n*8 <= self.device_output_limit:
-                out = DeviceSpectra(engine, temperature.size, n)
-            result = data.gas.absorption_coefficients(
-                temperature, pressure, mole_fraction.ravel(), self.grid,
-                remove_pedestal=remove_pedestal, range_policy=range_policy,
-                scale_density=True, out=out, asynchronous=out is not None)
-            pending[name] = (engine, result)
-        if sum_on_device:
-            total = np.zeros((temperature.size, self.grid.size))
-            if summed is not None:
-                summed[0].synchronize()
-                total = np.ascontiguousarray(summed[1].to_host()[:, :self.grid.size])
-                summed[1].free()
+                    scale_density=True, out=lines_sum.buffer, accumulate=lines_sum.take(),
+                    asynchronous=True)
+            for continuum in continua_here:
+                continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
+                                         out=continuum_sum.buffer,
+                                         accumulate=continuum_sum.take(), asynchronous=True)
+        if engine is not None:
+            engine.synchronize()
+
+        def fetch(key):
+            block = blocks.get(key)
+            if block is None:
+                return None
+            return block.to_host(columns) if isinstance(block, _Sum) else block
+
+        if mode == "total":
+            values = np.zeros((levels, columns))
+            if total is not None:
+                values = total.to_host(columns)
+            for block in blocks.values():           # host blocks of the too-large case
+                values = values + block
             return self._create_output_dataset(
-                {"total": total.reshape(list(shape) + [self.grid.size])}, output_format)
+                {"total": values.reshape(shape + [columns])}, output_format)
         beta = {}
         for name in self.atmosphere.gases:
             varname = "{}_absorption".format(name)
-            lines = np.zeros((temperature.size, self.grid.size))
-            if name in pending:
-                engine, result = pending[name]
-                if isinstance(result, DeviceSpectra):
-                    engine.synchronize()
-                    lines = result.to_host()[:, :self.grid.size]
-                    result.free()
-                else:
-                    lines = result[:, :self.grid.size]
-            if output_format == "all":
-                values = np.zeros([temperature.size, len(MECHANISMS), self.grid.size])
-                values[:, 0, :] = lines
+            lines, continuum = fetch((name, 0)), fetch((name, 1))
+            if mode == "all":
+                values = np.zeros([levels, len(MECHANISMS), columns])
+                if lines is not None:
+                    values[:, 0, :] = lines
+                if continuum is not None:
+                    values[:, 1, :] = continuum
                 beta[varname] = values.reshape(self.output.dim_sizes)
             else:
-                beta[varname] = np.ascontiguousarray(lines).reshape(
-                    list(shape) + [self.grid.size])
+                values = np.zeros((levels, columns))
+                for part in (lines, continuum):
+                    if part is not None:
+                        values = values + part
+                beta[varname] = values.reshape(shape + [columns])
         return self._create_output_dataset(beta, output_format)
 
     def _create_output_dataset(self, absorption, output_format):

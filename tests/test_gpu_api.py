@@ -80,7 +80,7 @@ def test_spectroscopy_lines_slot(small_database, oracle):
         for formula in ("H2O", "CO2"):
             beta = np.asarray(out[f"{formula}_absorption"])
             assert beta.shape == (4, 3, grid.size)
-            assert not beta[:, 1:, :].any()
+            assert beta[:, 1, :].any() and not beta[:, 2, :].any()   # slot 1: test_gpu_continuum
             for level in range(4):
                 t, p, x = atmos.t[level], atmos.p[level], atmos.vmr[formula][level]
                 k_ref, _ = oracle.absorption_port(tables[formula], t, p, x, v0, vn, npv,
@@ -93,7 +93,7 @@ def test_spectroscopy_lines_slot(small_database, oracle):
     assert np.asarray(per_gas["H2O_absorption"]).shape == (4, grid.size)
     np.testing.assert_allclose(np.asarray(total["absorption"]),
                                np.asarray(per_gas["H2O_absorption"]) +
-                               np.asarray(per_gas["CO2_absorption"]), rtol=1e-14)
+                               np.asarray(per_gas["CO2_absorption"]), rtol=1e-13)
     # Same with the pedestal removed (the default): the on-device sum goes through the
     # un-pedestalled scratch buffer + pedestal_apply_kernel's accumulate form.
     per_gas = spec.compute_absorption(output_format="gas")
