@@ -199,6 +199,69 @@ def cpu_baseline_parallel(tables, atmos, v0, n_per_v, sample_cm, workers):
                       f"units, {evals:.4g} evals in {seconds:.2f} s"}
 
 
+def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
+    """Times the continuum kernels (pylbl_amd/csrc/continuum.h) for the gases of the workload
+    that have an MT-CKD continuum.  Needs the coefficient tables ($PYLBL_MT_CKD, an installed
+    pyLBL, or the fixture under tests/golden); returns None without them."""
+    from pylbl_amd import mt_ckd, mt_ckd_data
+    from pylbl_amd.engine import DeviceSpectra
+    try:
+        path = mt_ckd_data.default_path()
+    except FileNotFoundError:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden",
+                            "mt_ckd_bands.npz")
+        if not os.path.isfile(path):
+            return None
+    owners = []
+    for formula in molecules:
+        owners += ["H2OForeign", "H2OSelf"] if formula == "H2O" else \
+            [formula] if formula in mt_ckd.CONTINUA else []
+    if not owners:
+        return None
+    grid = np.arange(v_lo, v_hi, dv)
+    continua = [mt_ckd.CONTINUA[owner](path=path, engine=engine) for owner in owners]
+    t, p = atmos.t[mine], atmos.p[mine]
+    vmr = {formula: values[mine] for formula, values in atmos.vmr.items()}
+    block = DeviceSpectra(engine, t.size, grid.size)
+
+    def step():
+        for i, continuum in enumerate(continua):
+            continuum.spectra_levels(t, p, vmr, grid, out=block, accumulate=i > 0,
+                                     asynchronous=True)
+    for _ in range(2):
+        step()
+    engine.synchronize()
+    engine.set_option("timing", 1)
+    engine.timing(reset=True)
+    start = time.perf_counter()
+    for _ in range(steps):
+        step()
+    engine.synchronize()
+    elapsed = time.perf_counter() - start
+    kernel_ms, launches = engine.timing(reset=True)
+    engine.set_option("timing", 0)
+    block.free()
+    # Algorithmic bytes per launch: wavenumber in + extinction out per point and level, plus
+    # the extinction read back by the launches that add to it.
+    adding = len(continua) - 1
+    bytes_per_step = grid.size*t.size*(16*len(continua) + 8*adding)
+    interp_seconds = kernel_ms[5]*1e-3/steps
+    achieved = bytes_per_step/interp_seconds/1e9
+    return {
+        "workload": f"MT-CKD continua {'+'.join(owners)} summed into one [levels, points] block "
+                    f"in HBM, {t.size} level(s), {grid.size} points",
+        "ms_per_step": elapsed/steps*1e3,
+        "spectra_per_s": t.size*steps/elapsed,
+        "kernel_ms_per_step": {"band_spectra": kernel_ms[4]/steps, "interpolate": kernel_ms[5]/steps},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "lbl::continuum_interp_kernel",
+                     "avg_launch_ms": kernel_ms[5]/max(launches[5], 1),
+                     "note": "16 algorithmic bytes per point and level (wavenumber in, extinction "
+                             "out; +8 when adding into the block); HIP events on the engine's stream"},
+    }
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -358,6 +421,12 @@ def main():
                     "at the same 1e-6 bar",
         }
 
+    # Not part of `value` either: mechanism slot 1 (MT-CKD continua) for the same gases, levels
+    # and grid, written into the same kind of HBM block.
+    continuum_extra = None
+    if world == 1 and not args.ablate and not args.host_output and not args.no_extras:
+        continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps)
+
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
                          device="cpu" if on_host else "cuda")
     if world > 1:
@@ -417,6 +486,8 @@ def main():
         }
         if farfield_extra is not None:
             line["farfield_option"] = farfield_extra
+        if continuum_extra is not None:
+            line["continuum_slot"] = continuum_extra
         if args.host_output:
             line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
         traffic, source = profiled_traffic(line["config"]["workload"])

@@ -92,14 +92,17 @@ int lbl_compute(lbl_engine *engine, int32_t molecule, int32_t n_levels,
 /* Waits for everything enqueued on the engine's stream. */
 int lbl_synchronize(lbl_engine *engine);
 
-/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic), "timing" (0/1: record
- * HIP events around every kernel), "tile_order" (0 natural, 1 heaviest first). */
+/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1:
+ * record HIP events around every kernel), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
+ * pre-pass on a side stream, default 1), "scan_chain" (0/1: parallel form of the pedestal
+ * chain where it applies, default 1), "farfield" (0/1: distant lines by power series, default
+ * 0), "aligned_tiles" (0/1), "ablate" (timing diagnostics only). */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
 /* With option timing=1: accumulated kernel milliseconds and launch counts since the last
- * reset; index 0 line-scalar prep, 1 tile schedule, 2 Voigt accumulate, 3 pedestal.
- * Synchronizes the stream. */
-int lbl_timing(lbl_engine *engine, double ms[4], int64_t launches[4], int32_t reset);
+ * reset; index 0 line-scalar prep, 1 tile schedule, 2 Voigt accumulate, 3 pedestal,
+ * 4 continuum band spectra, 5 continuum interpolation.  Synchronizes the streams. */
+int lbl_timing(lbl_engine *engine, double ms[6], int64_t launches[6], int32_t reset);
 
 /* The engine's HIP stream (a hipStream_t), for callers that time with their own events. */
 void *lbl_stream(lbl_engine *engine);

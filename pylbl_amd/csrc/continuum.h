@@ -193,69 +193,152 @@ __device__ inline double band_value(const Band & b, const double * __restrict__ 
     }
 }
 
-// grid = (coarse points of the widest band / 256, bands, levels).
+// grid = (coarse points of the widest band / 256, bands, levels).  Besides the spectrum the
+// kernel stores the slope of every coarse interval, (fp[j+1]-fp[j])/(xp[j+1]-xp[j]): what
+// numpy.interp precomputes when the target grid is longer than the table.
 __global__ __launch_bounds__(256) void band_spectra_kernel(BandSet set,
                                                            const double * __restrict__ table,
                                                            const ContinuumLevel * __restrict__ levels,
-                                                           double * __restrict__ coarse)
+                                                           double * __restrict__ coarse,
+                                                           double * __restrict__ slopes)
 {
     const Band & b = set.band[blockIdx.y];
     const int j = blockIdx.x*256 + threadIdx.x;
     if (j >= b.size) return;
     const ContinuumLevel s = levels[blockIdx.z];
-    coarse[(long long)blockIdx.z*set.coarse_points + b.spectrum + j] = band_value(b, table, s, j);
+    const long long at = (long long)blockIdx.z*set.coarse_points + b.spectrum + j;
+    const double here = band_value(b, table, s, j);
+    coarse[at] = here;
+    double slope = 0.;
+    if (j + 1 < b.size)
+    {
+        const double xj = b.lower + (double)j*b.resolution;
+        const double xn = b.lower + (double)(j + 1)*b.resolution;
+        slope = (band_value(b, table, s, j + 1) - here)/(xn - xj);
+    }
+    slopes[at] = slope;
 }
 
-// numpy.interp(x, xp, fp, left=0, right=0) for one band with xp[j] = lower + j*resolution
+// continuum_interp_kernel<PT, LV>: PT points per thread (256 apart: coalesced 8 B accesses)
+// for LV levels.
+
+// numpy.interp(x, xp, fp, left=0, right=0) for every band, xp[j] = lower + j*resolution
 // (numpy/core/src/multiarray/compiled_base.c, arr_interp: interval by search, then
 // slope*(x - xp[j]) + fp[j], fp[j] itself on a knot, the same fallbacks for a NaN result).
-__device__ __forceinline__ double band_interp(const Band & b, const double * __restrict__ fp,
-                                              double x)
-{
-    const int last = b.size - 1;
-    const double x_first = b.lower;
-    const double x_last = b.lower + (double)last*b.resolution;
-    if (!(x >= x_first) || !(x <= x_last)) return 0.;     // also drops a NaN wavenumber
-    int j = (int)((x - b.lower)/b.resolution);
-    j = j < 0 ? 0 : (j > last ? last : j);
-    // Largest j with xp[j] <= x, whatever the rounding of the quotient did.
-    while (j < last && b.lower + (double)(j + 1)*b.resolution <= x) ++j;
-    while (j > 0 && b.lower + (double)j*b.resolution > x) --j;
-    const double xj = b.lower + (double)j*b.resolution;
-    const double fj = fp[j];
-    if (j == last || xj == x) return fj;
-    const double xn = b.lower + (double)(j + 1)*b.resolution;
-    const double fn = fp[j + 1];
-    const double slope = (fn - fj)/(xn - xj);
-    double value = slope*(x - xj) + fj;
-    if (value != value)
-    {
-        value = slope*(x - xn) + fn;
-        if (value != value && fj == fn) value = fj;
-    }
-    return value;
-}
-
-// grid = (points / 256, levels).  extinction[level][i] (+)= 100 * sum over bands.
+// The coarse grids are uniform, so the interval comes from one multiplication and at most a
+// step of correction; it does not depend on the level, so a thread keeps its points for
+// kInterpLevels levels: the wavenumber is read once, the interval found once per band.
+// The kernel is bound by the latency of two dependent round trips (wavenumber from HBM, then
+// the coarse spectrum from L2), so every thread carries kInterpPoints independent points.
+//
+// grid = (points / (256 PT), levels / LV).  extinction[level][i] (+)= 100 * sum over bands.
+template <int kInterpPoints, int kInterpLevels>
 __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
                                                                const double * __restrict__ coarse,
+                                                               const double * __restrict__ slopes,
                                                                const double * __restrict__ wavenumber,
-                                                               long long n, double * __restrict__ out,
+                                                               long long n, int n_levels,
+                                                               double * __restrict__ out,
                                                                long long level_stride, int accumulate)
 {
-    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
-    if (i >= n) return;
-    const double x = wavenumber[i];
-    const double * spectra = coarse + (long long)blockIdx.y*set.coarse_points;
-    double total = 0.;
+    const long long first = (long long)blockIdx.x*(256*kInterpPoints) + threadIdx.x;
+    const int level0 = blockIdx.y*kInterpLevels;
+    const int count = min(kInterpLevels, n_levels - level0);
+    double x[kInterpPoints];
+#pragma unroll
+    for (int p = 0; p < kInterpPoints; ++p)
+    {
+        const long long i = first + p*256;
+        x[p] = i < n ? wavenumber[i] : __builtin_nan("");
+    }
+    double total[kInterpPoints][kInterpLevels], before[kInterpPoints][kInterpLevels];
+#pragma unroll
+    for (int p = 0; p < kInterpPoints; ++p)
+    {
+        const long long i = first + p*256;
+#pragma unroll
+        for (int l = 0; l < kInterpLevels; ++l)
+        {
+            total[p][l] = 0.;
+            // What is already there, fetched beside the wavenumbers rather than at the end.
+            before[p][l] = (accumulate && i < n && l < count)
+                               ? out[(long long)(level0 + l)*level_stride + i] : 0.;
+        }
+    }
     for (int k = 0; k < set.n_bands; ++k)
     {
         const Band & b = set.band[k];
-        total += band_interp(b, spectra + b.spectrum, x)*100.;      // utils.py:171-173
+        const int last = b.size - 1;
+        const double x_last = b.lower + (double)last*b.resolution;
+        const double per_step = 1./b.resolution;
+        int j[kInterpPoints];
+        double dx[kInterpPoints];
+        bool inside[kInterpPoints], on_knot[kInterpPoints];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < kInterpPoints; ++p)
+        {
+            inside[p] = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
+            int at = inside[p] ? (int)((x[p] - b.lower)*per_step) : 0;
+            at = at < 0 ? 0 : (at > last ? last : at);
+            if (inside[p])
+            {
+                // Largest j with xp[j] <= x, whatever the rounding of the product did.
+                while (at < last && b.lower + (double)(at + 1)*b.resolution <= x[p]) ++at;
+                while (at > 0 && b.lower + (double)at*b.resolution > x[p]) --at;
+            }
+            const double xj = b.lower + (double)at*b.resolution;
+            j[p] = at;
+            dx[p] = x[p] - xj;
+            on_knot[p] = (at == last || xj == x[p]);
+            any = any || inside[p];
+        }
+        if (__ballot(any) == 0ull) continue;          // the whole wavefront lies outside
+        const long long base = (long long)level0*set.coarse_points + b.spectrum;
+        double f[kInterpPoints][kInterpLevels], slope[kInterpPoints][kInterpLevels];
+#pragma unroll
+        for (int p = 0; p < kInterpPoints; ++p)
+        {
+#pragma unroll
+            for (int l = 0; l < kInterpLevels; ++l)
+            {
+                const long long at = base + (long long)(l < count ? l : 0)*set.coarse_points + j[p];
+                f[p][l] = coarse[at];
+                slope[p][l] = slopes[at];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kInterpPoints; ++p)
+        {
+#pragma unroll
+            for (int l = 0; l < kInterpLevels; ++l)
+            {
+                double value = on_knot[p] ? f[p][l] : slope[p][l]*dx[p] + f[p][l];
+                if (value != value && inside[p] && !on_knot[p] && l < count)
+                {
+                    const long long at = base + (long long)l*set.coarse_points + j[p];
+                    const double xn = b.lower + (double)(j[p] + 1)*b.resolution;
+                    const double fn = coarse[at + 1];
+                    value = slope[p][l]*(x[p] - xn) + fn;
+                    if (value != value && f[p][l] == fn) value = f[p][l];
+                }
+                if (inside[p]) total[p][l] += value*100.;         // utils.py:171-173
+            }
+        }
     }
-    double * target = out + (long long)blockIdx.y*level_stride + i;
-    if (accumulate) total += *target;
-    *target = total;
+#pragma unroll
+    for (int p = 0; p < kInterpPoints; ++p)
+    {
+        const long long i = first + p*256;
+        if (i >= n) continue;
+#pragma unroll
+        for (int l = 0; l < kInterpLevels; ++l)
+        {
+            if (l >= count) continue;
+            double * target = out + (long long)(level0 + l)*level_stride + i;
+            *target = accumulate ? total[p][l] + before[p][l] : total[p][l];
+        }
+    }
 }
 
 }  // namespace lbl

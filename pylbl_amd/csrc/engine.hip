@@ -124,7 +124,8 @@ struct Molecule
     }
 };
 
-enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3 };
+enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3,
+       kTimeBandSpectra = 4, kTimeContinuum = 5, kTimeKinds = 6 };
 
 // One in-flight compute call: its own pair of streams and its own workspace, so that
 // several molecules can be in the pipeline at once (the serial pedestal chain of one
@@ -202,6 +203,7 @@ struct ContinuumSet
     DeviceBuffer<double> table;
     DeviceBuffer<ContinuumLevel> levels;
     DeviceBuffer<double> coarse;        // [levels][set.coarse_points]
+    DeviceBuffer<double> slopes;        // same shape: slope of the interval after each knot
     DeviceBuffer<double> staging;       // extinction on its way to host memory
     int widest = 0;                     // points of the largest band
     // Level scalars go through a pinned block; `done` marks the last kernel that reads it
@@ -266,14 +268,15 @@ struct lbl_engine
     int aligned_tiles = 0;          // measured: no gain at 0.001 cm-1
     int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
+    int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double time_ms[4] = {0., 0., 0., 0.};
-    long long launches[4] = {0, 0, 0, 0};
+    double time_ms[kTimeKinds] = {};
+    long long launches[kTimeKinds] = {};
 
     hipEvent_t take_event()
     {
@@ -1139,6 +1142,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->timing = (int)value;
     }
+    else if (key == "interp_shape" && value >= 0 && value < 100)
+    {
+        engine->interp_shape = (int)value;
+    }
     else if (key == "scan_chain" && (value == 0 || value == 1))
     {
         engine->scan_chain = (int)value;
@@ -1170,7 +1177,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     return LBL_OK;
 }
 
-int lbl_timing(lbl_engine * engine, double ms[4], int64_t launches[4], int32_t reset)
+int lbl_timing(lbl_engine * engine, double ms[6], int64_t launches[6], int32_t reset)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
     try
@@ -1183,7 +1190,7 @@ int lbl_timing(lbl_engine * engine, double ms[4], int64_t launches[4], int32_t r
     {
         return fail(engine, LBL_ERROR, f.message);
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < kTimeKinds; ++i)
     {
         if (ms != nullptr) ms[i] = engine->time_ms[i];
         if (launches != nullptr) launches[i] = engine->launches[i];

@@ -299,9 +299,10 @@ class Engine(object):
         return np.split(spectra, np.cumsum(sizes)[:-1])
 
     def timing(self, reset=False):
-        """(milliseconds[4], launches[4]) for prepare, schedule, accumulate, pedestal."""
-        ms = (c_double*4)()
-        launches = (c_int64*4)()
+        """(milliseconds[6], launches[6]) for prepare, schedule, accumulate, pedestal,
+        continuum band spectra, continuum interpolation."""
+        ms = (c_double*6)()
+        launches = (c_int64*6)()
         self._check(self.lib.lbl_timing(self.handle, ms, launches, 1 if reset else 0))
         return list(ms), list(launches)
 
