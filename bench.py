@@ -61,6 +61,8 @@ def parse():
     parser.add_argument("--no-extras", action="store_true",
                         help="only the timed steps: no CPU baseline, no far-field extra pass "
                              "(what scripts/profile_bench.sh runs under rocprofv3)")
+    parser.add_argument("--extras", default="all", choices=["all", "none", "farfield", "continuum"],
+                        help="which untimed extra legs run after the timed steps")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; not the default)")
@@ -145,8 +147,8 @@ def cpu_baseline(tables, atmos, v0, n_per_v, sample_cm, remove_pedestal):
     }
 
 
-def profiled_traffic(workload):
-    """HBM bytes per accumulate launch from the newest committed rocprofv3 counter summary
+def profiled_traffic(workload, kernel="accumulate_kernel"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 counter summary
     (profiles/*_summary.json, made by scripts/profile_bench.sh + summarize_profile.py: separate
     FETCH_SIZE / WRITE_SIZE passes, KiB units, reads doubled per the gfx950 correction) -- only
     if that profile ran this same workload; the counters cannot be read from inside bench.py."""
@@ -158,7 +160,7 @@ def profiled_traffic(workload):
             if summary["bench_line"]["config"]["workload"] != workload:
                 continue
             for name, counters in summary["counters"].items():
-                if "accumulate_kernel" in name and "hbm_bytes_per_launch" in counters:
+                if kernel in name and "hbm_bytes_per_launch" in counters:
                     return counters["hbm_bytes_per_launch"], os.path.basename(path)
         except (OSError, KeyError, TypeError, ValueError):
             continue
@@ -275,6 +277,8 @@ def cpu_model():
 
 def main():
     args = parse()
+    if args.no_extras:
+        args.extras = "none"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -401,7 +405,7 @@ def main():
     # Not part of `value`: the same steps with the optional far-field series switched on.
     farfield_extra = None
     if world == 1 and not args.farfield and not args.ablate and not args.host_output and \
-            not args.no_extras:
+            args.extras in ("all", "farfield"):
         engine.set_option("farfield", 1)
         for _ in range(2):
             step()
@@ -424,7 +428,8 @@ def main():
     # Not part of `value` either: mechanism slot 1 (MT-CKD continua) for the same gases, levels
     # and grid, written into the same kind of HBM block.
     continuum_extra = None
-    if world == 1 and not args.ablate and not args.host_output and not args.no_extras:
+    if world == 1 and not args.ablate and not args.host_output and \
+            args.extras in ("all", "continuum"):
         continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps)
 
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
@@ -488,6 +493,10 @@ def main():
             line["farfield_option"] = farfield_extra
         if continuum_extra is not None:
             line["continuum_slot"] = continuum_extra
+            traffic, source = profiled_traffic(line["config"]["workload"], "continuum_interp_kernel")
+            if traffic is not None:
+                continuum_extra["roofline"]["traffic"] = traffic
+                continuum_extra["roofline"]["traffic_source"] = f"profiles/{source}"
         if args.host_output:
             line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
         traffic, source = profiled_traffic(line["config"]["workload"])

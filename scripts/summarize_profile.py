@@ -5,6 +5,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
@@ -13,7 +14,8 @@ src = f"gpurun_out/prof_{tag}"
 stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 "
-           "--warmup 2 --no-extras " + " ".join(sys.argv[2:]), "kernels": {}, "counters": {}}
+           "--warmup 2 --no-cpu-baseline --extras " + os.environ.get("EXTRAS", "none") + " " +
+           " ".join(sys.argv[2:]), "kernels": {}, "counters": {}}
 for row in csv.DictReader(open(stats)):
     summary["kernels"][row["Name"].split("(")[0]] = {
         "calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"])/1e6,
