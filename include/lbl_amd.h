@@ -101,8 +101,9 @@ int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
 /* With option timing=1: accumulated kernel milliseconds and launch counts since the last
  * reset; index 0 line-scalar prep, 1 tile schedule, 2 Voigt accumulate, 3 pedestal,
- * 4 continuum band spectra, 5 continuum interpolation.  Synchronizes the streams. */
-int lbl_timing(lbl_engine *engine, double ms[6], int64_t launches[6], int32_t reset);
+ * 4 continuum band spectra, 5 continuum interpolation, 6 cross-section fit, 7 cross-section
+ * interpolation.  Synchronizes the streams. */
+int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t reset);
 
 /* The engine's HIP stream (a hipStream_t), for callers that time with their own events. */
 void *lbl_stream(lbl_engine *engine);
@@ -191,6 +192,35 @@ int lbl_continuum_compute(lbl_engine *engine, int32_t continuum, int32_t grid,
  * Continuum.spectra(temperature, pressure [mb], vmr) (utils.py:98-108). */
 int lbl_continuum_bands(lbl_engine *engine, int32_t continuum, double temperature,
                         double pressure_mb, const double *vmr, double *spectra);
+
+/* ---------------------------------------------------------------------------------------
+ * ARTS-crossfit absorption cross-sections: mechanism slot 2 of compute_absorption
+ * (pyLBL/spectroscopy.py:199-203).  Replaces CrossSection.absorption_coefficient
+ * (pyLBL/arts_crossfit/cross_section.py:19-48) and calculate_xsec_fullmodel
+ * (pyLBL/arts_crossfit/xsec_aux_functions.py:14-121).
+ * ------------------------------------------------------------------------------------- */
+#define LBL_MAX_XSEC_BANDS 16
+
+/* Uploads the bands of one molecule: sizes[n_bands] frequencies per band; `frequency` [Hz]
+ * concatenated over the bands, strictly ascending within a band; `coefficients` per band the
+ * [4][size] matrix p00, p10, p01, p20 of the fit z = p00 + p10 T + p01 P + p20 T^2,
+ * concatenated in band order. */
+int lbl_xsec_load(lbl_engine *engine, int32_t n_bands, const int32_t *sizes,
+                  const double *frequency, const double *coefficients, int32_t *xsec);
+int lbl_xsec_free(lbl_engine *engine, int32_t xsec);
+
+/* Cross sections [m2] at n_levels levels on a loaded grid (lbl_grid_load); with
+ * LBL_SCALE_DENSITY multiplied by P vmr /(kb T), i.e. slot 2 itself [m-1] (vmr may be NULL
+ * otherwise).  out / level_stride / LBL_OUT_DEVICE / LBL_ASYNC / LBL_ACCUMULATE as for
+ * lbl_continuum_compute. */
+int lbl_xsec_compute(lbl_engine *engine, int32_t xsec, int32_t grid, int32_t n_levels,
+                     const double *temperature, const double *pressure, const double *vmr,
+                     int32_t flags, double *out, int64_t level_stride);
+
+/* The fit with negative values removed on the bands' own frequency grids, concatenated in
+ * band order: calculate_xsec_fullmodel(temperature, pressure [Pa], coeffs) per band. */
+int lbl_xsec_bands(lbl_engine *engine, int32_t xsec, double temperature, double pressure,
+                   double *values);
 
 /* Same signature and semantics as the reference's absorption() (absorption.c:19-30):
  * opens the SQLite file, uploads the molecule (cached per path+formula for the life of the

@@ -5,8 +5,8 @@ Names mirror ``pyLBL/__init__.py:1-5`` for the lines path: ``Gas``, ``Database``
 first ``Gas``/``Engine`` does, and fails loudly if the HIP library or the device is missing.
 """
 from .database import Database, LineTable, TotalPartitionFunction, write_database
-from .errors import AliasNotFoundError, EngineError, IsotopologuesNotFoundError, \
-                    TipsDataNotFoundError, TransitionsNotFoundError
+from .errors import AliasNotFoundError, CrossSectionNotFoundError, EngineError, \
+                    IsotopologuesNotFoundError, TipsDataNotFoundError, TransitionsNotFoundError
 from .engine import DeviceSpectra, Engine, default_engine
 from .gas_optics import Gas
 from .plugins import continua, cross_sections, models, molecular_lines, register
@@ -15,5 +15,5 @@ from .spectroscopy import Atmosphere, Spectroscopy, number_density
 __all__ = ["Gas", "Database", "LineTable", "TotalPartitionFunction", "write_database",
            "Engine", "DeviceSpectra", "default_engine", "Spectroscopy", "Atmosphere",
            "number_density", "molecular_lines", "continua", "cross_sections", "models",
-           "register", "AliasNotFoundError", "EngineError", "IsotopologuesNotFoundError",
+           "register", "AliasNotFoundError", "CrossSectionNotFoundError", "EngineError", "IsotopologuesNotFoundError",
            "TipsDataNotFoundError", "TransitionsNotFoundError"]

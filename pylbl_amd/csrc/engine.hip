@@ -22,6 +22,7 @@
 #include "../../include/lbl_amd.h"
 #include "accumulate.h"
 #include "continuum.h"
+#include "xsec.h"
 #include "farfield.h"
 #include "line_prep.h"
 #include "pedestal.h"
@@ -125,7 +126,8 @@ struct Molecule
 };
 
 enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3,
-       kTimeBandSpectra = 4, kTimeContinuum = 5, kTimeKinds = 6 };
+       kTimeBandSpectra = 4, kTimeContinuum = 5, kTimeXsecModel = 6, kTimeXsec = 7,
+       kTimeKinds = 8 };
 
 // One in-flight compute call: its own pair of streams and its own workspace, so that
 // several molecules can be in the pipeline at once (the serial pedestal chain of one
@@ -195,20 +197,14 @@ struct Lane
 
 constexpr int kLanes = 8;
 
-// One continuum (continuum.h): its bands, their coefficient table and the per-level
-// workspace of coarse spectra.
-struct ContinuumSet
+// Level scalars of a batched call on their way to the device: a pinned block, its device
+// copy and an event that marks the last kernel reading them (and the per-level workspace that
+// goes with them), so that a later call on the same object waits for that only.
+template <typename Level>
+struct LevelFeed
 {
-    BandSet set;
-    DeviceBuffer<double> table;
-    DeviceBuffer<ContinuumLevel> levels;
-    DeviceBuffer<double> coarse;        // [levels][set.coarse_points]
-    DeviceBuffer<double> slopes;        // same shape: slope of the interval after each knot
-    DeviceBuffer<double> staging;       // extinction on its way to host memory
-    int widest = 0;                     // points of the largest band
-    // Level scalars go through a pinned block; `done` marks the last kernel that reads it
-    // and the coarse spectra, so that a later call waits for that only.
-    ContinuumLevel * pinned = nullptr;
+    DeviceBuffer<Level> levels;
+    Level * pinned = nullptr;
     size_t pinned_capacity = 0;
     hipEvent_t done = nullptr;
     bool in_flight = false;
@@ -229,20 +225,47 @@ struct ContinuumSet
         if (count <= pinned_capacity) return;
         if (pinned != nullptr) (void)hipHostFree(pinned);
         pinned = nullptr;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), count*sizeof(ContinuumLevel),
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), count*sizeof(Level),
                               hipHostMallocDefault));
         pinned_capacity = count;
     }
-    ~ContinuumSet()
+    ~LevelFeed()
     {
         if (done != nullptr) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); }
         if (pinned != nullptr) (void)hipHostFree(pinned);
     }
+    LevelFeed() = default;
+    LevelFeed(const LevelFeed &) = delete;
+    LevelFeed & operator=(const LevelFeed &) = delete;
+};
+
+// One continuum (continuum.h): its bands, their coefficient table and the per-level
+// workspace of coarse spectra.
+struct ContinuumSet : LevelFeed<ContinuumLevel>
+{
+    BandSet set;
+    DeviceBuffer<double> table;
+    DeviceBuffer<double> coarse;        // [levels][set.coarse_points]
+    DeviceBuffer<double> slopes;        // same shape: slope of the interval after each knot
+    DeviceBuffer<double> staging;       // extinction on its way to host memory
+    int widest = 0;                     // points of the largest band
+};
+
+// The cross-section bands of one molecule (xsec.h).
+struct XsecData : LevelFeed<XsecLevel>
+{
+    XsecSet set;
+    DeviceBuffer<double> fgrid;         // concatenated band frequency grids [Hz]
+    DeviceBuffer<double> coeffs;        // per band [4][size]
+    DeviceBuffer<double> values;        // [levels][set.total]: the fit on the bands' grids
+    DeviceBuffer<double> slopes;        // same shape
+    DeviceBuffer<double> staging;
 };
 
 struct SpectralGrid
 {
     long long n = 0;
+    bool ascending = true;
     DeviceBuffer<double> wavenumber;
 };
 
@@ -256,6 +279,7 @@ struct lbl_engine
     std::vector<std::unique_ptr<Molecule>> molecules;
     std::vector<std::unique_ptr<ContinuumSet>> continua;
     std::vector<std::unique_ptr<SpectralGrid>> grids;
+    std::vector<std::unique_ptr<XsecData>> xsecs;
     Lane lanes[kLanes];
     unsigned next_lane = 0;
 
@@ -965,6 +989,7 @@ int lbl_engine_destroy(lbl_engine * engine)
     for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
     engine->molecules.clear();
     engine->continua.clear();
+    engine->xsecs.clear();
     engine->grids.clear();
     for (auto & lane : engine->lanes) lane.destroy();
     delete engine;
@@ -1177,7 +1202,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     return LBL_OK;
 }
 
-int lbl_timing(lbl_engine * engine, double ms[6], int64_t launches[6], int32_t reset)
+int lbl_timing(lbl_engine * engine, double ms[8], int64_t launches[8], int32_t reset)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
     try
@@ -1244,4 +1269,5 @@ int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int6
 }  // extern "C"
 
 #include "continuum_entry.inc"
+#include "xsec_entry.inc"
 #include "sqlite_entry.inc"

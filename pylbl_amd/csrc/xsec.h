@@ -1,0 +1,220 @@
+// ARTS-crossfit absorption cross-sections on the device: the counterpart of the reference's
+// mechanism slot 2 (pyLBL/spectroscopy.py:199-203 -> CrossSection.absorption_coefficient,
+// pyLBL/arts_crossfit/cross_section.py:19-48).
+//
+// A molecule has a few bands; a band has a frequency grid [Hz] and four fit coefficients per
+// frequency.  Per level the reference evaluates p00 + p10 T + p01 P + p20 T^2 on the band's
+// grid, removes negative values without changing the band integral
+// (xsec_aux_functions.py:80-121), interpolates linearly to the user's grid converted to Hz
+// (scipy interp1d, zero outside the band) and adds the bands up.
+//
+// Two kernels:
+//   xsec_model_kernel    workgroup = one (band, level): fit, the two sums the clipping rule
+//                        needs (workgroup reduction), rescale, slope of every interval;
+//   xsec_interp_kernel   thread = PT points of the user's grid x LV levels: the band grids are
+//                        not uniform, so the interval comes from a binary search -- narrowed
+//                        per workgroup to the few intervals its (ascending) points span.
+//                        HBM-bound like continuum_interp_kernel: 16 B per point and level.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace lbl {
+
+constexpr int kMaxXsecBands = 16;
+constexpr double kSpeedOfLight = 299792458.0;       // cross_section.py:31
+constexpr double kBoltzmann = 1.38064852e-23;       // spectroscopy.py:15
+
+struct XsecBand
+{
+    int size;               // frequencies
+    long long offset;       // of this band in the concatenated frequency axis
+};
+
+struct XsecSet
+{
+    int n_bands;
+    int total;              // sum of sizes = workspace doubles per level
+    XsecBand band[kMaxXsecBands];
+};
+
+struct XsecLevel
+{
+    double t, p;            // [K], [Pa]
+    double density;         // P x /(kb T) [m-3] (spectroscopy.py:18-29), 1 if not scaled
+};
+
+__device__ __forceinline__ double block_sum(double value, double * scratch)
+{
+    // 256 threads = 4 wavefronts; fixed order, so the result does not depend on timing.
+    for (int offset = 32; offset > 0; offset >>= 1) value += __shfl_down(value, offset, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = value;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// grid = (bands, levels), 256 threads.  coeffs: per band [4][size] at 4*offset.
+__global__ __launch_bounds__(256) void xsec_model_kernel(XsecSet set,
+                                                         const double * __restrict__ fgrid,
+                                                         const double * __restrict__ coeffs,
+                                                         const XsecLevel * __restrict__ levels,
+                                                         double * __restrict__ values,
+                                                         double * __restrict__ slopes)
+{
+    __shared__ double scratch[4];
+    const XsecBand b = set.band[blockIdx.x];
+    const XsecLevel s = levels[blockIdx.y];
+    const double * c = coeffs + 4*b.offset;
+    double * out = values + (long long)blockIdx.y*set.total + b.offset;
+    double * slope = slopes + (long long)blockIdx.y*set.total + b.offset;
+    const double * f = fgrid + b.offset;
+    const double tt = s.t*s.t;
+    double raw_sum = 0., kept_sum = 0., negatives = 0.;
+    for (int j = threadIdx.x; j < b.size; j += 256)
+    {
+        // Rows added in the reference's order (xsec_aux_functions.py:49-75).
+        const double value = ((c[j]*1. + c[b.size + j]*s.t) + c[2*b.size + j]*s.p) +
+                             c[3*b.size + j]*tt;
+        out[j] = value;
+        raw_sum += value;
+        if (value < 0.) negatives += 1.; else kept_sum += value;
+    }
+    raw_sum = block_sum(raw_sum, scratch);
+    kept_sum = block_sum(kept_sum, scratch);
+    negatives = block_sum(negatives, scratch);
+    if (negatives > 0.)
+    {
+        // xsec_aux_functions.py:104-119: clip; rescale only when the integral was not negative.
+        const double weight = raw_sum >= 0. ? raw_sum/kept_sum : 1.;
+        const bool rescale = raw_sum >= 0.;
+        for (int j = threadIdx.x; j < b.size; j += 256)
+        {
+            double value = out[j];
+            value = value < 0. ? 0. : value;
+            out[j] = rescale ? value*weight : value;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < b.size; j += 256)
+    {
+        slope[j] = j + 1 < b.size ? (out[j + 1] - out[j])/(f[j + 1] - f[j]) : 0.;
+    }
+}
+
+// First index with f[index] >= x within [lo, hi] (numpy.searchsorted, side="left").
+__device__ __forceinline__ int lower_bound(const double * __restrict__ f, int lo, int hi, double x)
+{
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (f[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// grid = (points / (256 PT), levels / LV).  out[level][i] (+)= density * sum over bands.
+template <int PT, int LV>
+__global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
+                                                          const double * __restrict__ fgrid,
+                                                          const double * __restrict__ values,
+                                                          const double * __restrict__ slopes,
+                                                          const XsecLevel * __restrict__ levels,
+                                                          const double * __restrict__ wavenumber,
+                                                          long long n, int n_levels, int ascending,
+                                                          double * __restrict__ out,
+                                                          long long level_stride, int accumulate)
+{
+    __shared__ int window[kMaxXsecBands][2];
+    const long long block_first = (long long)blockIdx.x*(256*PT);
+    const long long first = block_first + threadIdx.x;
+    const int level0 = blockIdx.y*LV;
+    const int count = min(LV, n_levels - level0);
+    // Search window of every band for this workgroup's points: exact when the grid ascends.
+    if (threadIdx.x < set.n_bands)
+    {
+        const XsecBand b = set.band[threadIdx.x];
+        int lo = 0, hi = b.size;
+        if (ascending)
+        {
+            const long long block_last = min(block_first + 256*PT, n) - 1;
+            const double x_lo = wavenumber[block_first]*kSpeedOfLight*100;
+            const double x_hi = wavenumber[block_last]*kSpeedOfLight*100;
+            lo = lower_bound(fgrid + b.offset, 0, b.size, x_lo);
+            hi = lower_bound(fgrid + b.offset, lo, b.size, x_hi);
+        }
+        window[threadIdx.x][0] = lo;
+        window[threadIdx.x][1] = hi;
+    }
+    double x[PT], total[PT][LV], before[PT][LV];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+        const long long i = first + p*256;
+        // Hz, as the reference forms it (cross_section.py:32).
+        x[p] = i < n ? wavenumber[i]*kSpeedOfLight*100 : __builtin_nan("");
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+        {
+            total[p][l] = 0.;
+            before[p][l] = (accumulate && i < n && l < count)
+                               ? out[(long long)(level0 + l)*level_stride + i] : 0.;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < set.n_bands; ++k)
+    {
+        const XsecBand b = set.band[k];
+        const double * f = fgrid + b.offset;
+        const double f_first = f[0], f_last = f[b.size - 1];
+        int j[PT];
+        double dx[PT];
+        bool inside[PT];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+        {
+            inside[p] = (x[p] >= f_first) && (x[p] <= f_last);     // zero outside (fill_value)
+            int at = 1;
+            if (inside[p])
+            {
+                // scipy interp1d (linear): searchsorted, clipped to [1, size-1]; the interval
+                // is (at-1, at).
+                at = lower_bound(f, window[k][0], window[k][1], x[p]);
+                at = at < 1 ? 1 : (at > b.size - 1 ? b.size - 1 : at);
+            }
+            j[p] = at - 1;
+            dx[p] = inside[p] ? x[p] - f[at - 1] : 0.;
+            any = any || inside[p];
+        }
+        if (__ballot(any) == 0ull) continue;
+        const long long base = (long long)level0*set.total + b.offset;
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+        {
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+            {
+                const long long at = base + (long long)(l < count ? l : 0)*set.total + j[p];
+                const double value = slopes[at]*dx[p] + values[at];
+                if (inside[p]) total[p][l] += value;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+        const long long i = first + p*256;
+        if (i >= n) continue;
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+        {
+            if (l >= count) continue;
+            const double value = levels[level0 + l].density*total[p][l];
+            out[(long long)(level0 + l)*level_stride + i] = accumulate ? value + before[p][l] : value;
+        }
+    }
+}
+
+}  // namespace lbl

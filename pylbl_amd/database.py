@@ -22,7 +22,7 @@ import sqlite3
 
 import numpy as np
 
-from .errors import AliasNotFoundError, IsotopologuesNotFoundError, \
+from .errors import AliasNotFoundError, CrossSectionNotFoundError, IsotopologuesNotFoundError, \
                     TipsDataNotFoundError, TransitionsNotFoundError
 
 
@@ -119,6 +119,23 @@ class Database(object):
             raise AliasNotFoundError(f"{name} not found in database.")
         return int(row[0])
 
+    def arts_crossfit(self, name):
+        """Path of the molecule's cross-section coefficient file (pyLBL/database.py:397-415).
+
+        Raises:
+            CrossSectionNotFoundError if the database lists none.
+        """
+        with self._connect() as connection:
+            id = self._molecule_id(connection, name)
+            try:
+                row = connection.execute(
+                    "select path from artscrossfit where molcule_id == ?", (id,)).fetchone()
+            except sqlite3.OperationalError:
+                row = None
+        if row is None:
+            raise CrossSectionNotFoundError(f"No cross sections for {name}.")
+        return row[0]
+
     def molecules(self):
         """Lists the chemical formulae of all molecules in the database."""
         with self._connect() as connection:
@@ -207,7 +224,7 @@ CREATE TABLE metadata (id INTEGER NOT NULL, molecule_id INTEGER, database VARCHA
 """
 
 
-def write_database(path, tables, with_tips=None, aliases=None):
+def write_database(path, tables, with_tips=None, aliases=None, cross_sections=None):
     """Writes LineTables into a fresh SQLite file with the reference's schema.
 
     Used for fixtures and benchmarks (no HITRAN data exists offline).  Row order of
@@ -219,6 +236,8 @@ def write_database(path, tables, with_tips=None, aliases=None):
         tables: Iterable of LineTable.
         with_tips: Optional set of formulae to write TIPS rows for (default: all).
         aliases: Optional dict formula -> extra alias strings.
+        cross_sections: Optional dict formula -> path of its ARTS-crossfit coefficient file
+                        (table artscrossfit, pyLBL/database.py:472-477).
     """
     import os
     if os.path.exists(path):
@@ -252,6 +271,10 @@ def write_database(path, tables, with_tips=None, aliases=None):
                     "insert into tips (molecule_id, isotopologue_id, temperature, data) "
                     "values (?, ?, ?, ?)",
                     zip([id]*num_t, [iso]*num_t, t, table.tips_data[iso].tolist()))
+    for table in tables:
+        if cross_sections and table.formula in cross_sections:
+            connection.execute("insert into artscrossfit (molcule_id, path) values (?, ?)",
+                               (int(table.molecule_id), str(cross_sections[table.formula])))
     connection.commit()
     connection.close()
     return str(path)

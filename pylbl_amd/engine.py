@@ -28,10 +28,12 @@ EXPORTED_SYMBOLS = (
     "lbl_line_scalars", "lbl_absorption", "lbl_version",
     "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
     "lbl_continuum_compute", "lbl_continuum_bands",
+    "lbl_xsec_load", "lbl_xsec_free", "lbl_xsec_compute", "lbl_xsec_bands",
 )
 
 VMR_SELF, VMR_H2O, VMR_O2, VMR_N2, VMR_TOTAL, VMR_COUNT = 0, 1, 2, 3, 4, 5
 MAX_BANDS = 8
+MAX_XSEC_BANDS = 16
 
 
 class BandDescriptor(Structure):
@@ -88,6 +90,11 @@ def library():
                                           c_void_p, c_void_p, c_int32, c_void_p, c_int64]
     lib.lbl_continuum_bands.argtypes = [c_void_p, c_int32, c_double, c_double, c_void_p,
                                         c_void_p]
+    lib.lbl_xsec_load.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, i32p]
+    lib.lbl_xsec_free.argtypes = [c_void_p, c_int32]
+    lib.lbl_xsec_compute.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                     c_void_p, c_int32, c_void_p, c_int64]
+    lib.lbl_xsec_bands.argtypes = [c_void_p, c_int32, c_double, c_double, c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("lbl_last_error", "lbl_stream", "lbl_version"):
             getattr(lib, name).restype = c_int32
@@ -273,21 +280,74 @@ class Engine(object):
         if not (t.ndim == 1 and t.shape == p.shape and x.shape[0] == t.size):
             raise ValueError("temperature, pressure [levels] and vmr [levels, 5] disagree.")
         flags = (ACCUMULATE if accumulate else 0) | (ASYNC if asynchronous else 0)
-        if out is None:
-            out = np.zeros((t.size, n), dtype=np.float64)
-        # Rows may be longer than the grid (the lines path pads them to whole wavenumbers).
-        if len(out.shape) != 2 or out.shape[0] != t.size or out.shape[1] < n:
-            raise ValueError(f"out has shape {out.shape}, need ({t.size}, >= {n}).")
-        if hasattr(out, "pointer"):
-            pointer, flags = out.pointer, flags | OUT_DEVICE
-        else:
-            if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
-                raise ValueError("out must be C-contiguous float64[levels, >= n].")
-            pointer = c_void_p(out.ctypes.data)
+        out, pointer, flags, stride = self._output(out, t.size, n, flags)
         self._check(self.lib.lbl_continuum_compute(
             self.handle, int(continuum), int(grid), t.size, t.ctypes.data, p.ctypes.data,
-            x.ctypes.data, flags, pointer, int(out.shape[1])))
+            x.ctypes.data, flags, pointer, stride))
         return out
+
+    def _output(self, out, levels, n, flags):
+        """(array or DeviceSpectra, pointer, flags, row stride) for a [levels, >= n] block."""
+        if out is None:
+            out = np.zeros((levels, n), dtype=np.float64)
+        # Rows may be longer than the grid (the lines path pads them to whole wavenumbers).
+        if len(out.shape) != 2 or out.shape[0] != levels or out.shape[1] < n:
+            raise ValueError(f"out has shape {out.shape}, need ({levels}, >= {n}).")
+        if hasattr(out, "pointer"):
+            return out, out.pointer, flags | OUT_DEVICE, int(out.shape[1])
+        if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be C-contiguous float64[levels, >= n].")
+        return out, c_void_p(out.ctypes.data), flags, int(out.shape[1])
+
+    # -- cross-sections (slot 2) -----------------------------------------------------------
+    def load_xsec(self, bands):
+        """Uploads [(frequency [Hz], coefficients [4, nfreq]), ...]; returns the handle."""
+        if not 1 <= len(bands) <= MAX_XSEC_BANDS:
+            raise ValueError(f"a molecule has 1 to {MAX_XSEC_BANDS} cross-section bands.")
+        sizes = np.zeros(len(bands), dtype=np.int32)
+        frequency, coefficients = [], []
+        for i, (f, c) in enumerate(bands):
+            f, c = _f64(f), _f64(c)
+            if f.ndim != 1 or c.shape != (4, f.size):
+                raise ValueError("a band is (frequency[nfreq], coefficients[4, nfreq]).")
+            sizes[i] = f.size
+            frequency.append(f)
+            coefficients.append(c.ravel())
+        frequency, coefficients = _f64(np.concatenate(frequency)), _f64(np.concatenate(coefficients))
+        handle = c_int32(-1)
+        self._check(self.lib.lbl_xsec_load(self.handle, len(bands), sizes.ctypes.data,
+                                           frequency.ctypes.data, coefficients.ctypes.data,
+                                           byref(handle)))
+        return handle.value
+
+    def free_xsec(self, xsec):
+        self._check(self.lib.lbl_xsec_free(self.handle, int(xsec)))
+
+    def xsec_compute(self, xsec, grid, n, temperature, pressure, vmr=None, out=None,
+                     accumulate=False, asynchronous=False):
+        """Cross sections [m2] (or, with vmr, n k [m-1]): float64[levels, n] or fills `out`."""
+        t, p = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure))
+        if not (t.ndim == 1 and t.shape == p.shape):
+            raise ValueError("temperature and pressure must be 1-d and equally long.")
+        flags = (ACCUMULATE if accumulate else 0) | (ASYNC if asynchronous else 0)
+        x = None
+        if vmr is not None:
+            x = _f64(np.atleast_1d(vmr))
+            if x.shape != t.shape:
+                raise ValueError("vmr must be shaped like temperature.")
+            flags |= SCALE_DENSITY
+        out, pointer, flags, stride = self._output(out, t.size, n, flags)
+        self._check(self.lib.lbl_xsec_compute(
+            self.handle, int(xsec), int(grid), t.size, t.ctypes.data, p.ctypes.data,
+            x.ctypes.data if x is not None else None, flags, pointer, stride))
+        return out
+
+    def xsec_bands(self, xsec, sizes, temperature, pressure):
+        """The clipped fit on the bands' own grids for one level (list of arrays)."""
+        values = np.zeros(int(sum(sizes)), dtype=np.float64)
+        self._check(self.lib.lbl_xsec_bands(self.handle, int(xsec), float(temperature),
+                                            float(pressure), values.ctypes.data))
+        return np.split(values, np.cumsum(sizes)[:-1])
 
     def continuum_bands(self, continuum, sizes, temperature, pressure_mb, vmr):
         """Coarse spectra [cm-1] of each band for one level (list of arrays)."""
@@ -299,10 +359,11 @@ class Engine(object):
         return np.split(spectra, np.cumsum(sizes)[:-1])
 
     def timing(self, reset=False):
-        """(milliseconds[6], launches[6]) for prepare, schedule, accumulate, pedestal,
-        continuum band spectra, continuum interpolation."""
-        ms = (c_double*6)()
-        launches = (c_int64*6)()
+        """(milliseconds[8], launches[8]) for prepare, schedule, accumulate, pedestal,
+        continuum band spectra, continuum interpolation, cross-section fit, cross-section
+        interpolation."""
+        ms = (c_double*8)()
+        launches = (c_int64*8)()
         self._check(self.lib.lbl_timing(self.handle, ms, launches, 1 if reset else 0))
         return list(ms), list(launches)
 

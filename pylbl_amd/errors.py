@@ -22,5 +22,9 @@ class TransitionsNotFoundError(BaseException):
     pass
 
 
+class CrossSectionNotFoundError(BaseException):
+    pass
+
+
 class EngineError(RuntimeError):
     """A non-zero status came back over the C-ABI (message from lbl_last_error)."""

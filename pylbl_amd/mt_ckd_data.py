@@ -10,12 +10,12 @@ well and is what ``tests/golden/mt_ckd_bands.npz`` is.
 Search order for the default table: ``$PYLBL_MT_CKD``, then the data file of an installed
 ``pyLBL`` package (located without importing it).
 """
-import ctypes
-import ctypes.util
 import importlib.util
 import os
 
 import numpy as np
+
+from . import hdf5_reader
 
 # Every variable the 16 bands read (water_vapor.py:20-21,53-54; carbon_dioxide.py:21-31;
 # nitrogen.py:16-17,37-38,61; oxygen.py:20,37,88,103,136; ozone.py:21,43-44,66).
@@ -38,72 +38,14 @@ class CoefficientTable(object):
         return self.lower_bound + np.arange(self.data.size)*self.resolution
 
 
-def _hdf5_library():
-    candidates = [ctypes.util.find_library("hdf5"), "libhdf5.so", "/opt/conda/lib/libhdf5.so"]
-    for name in candidates:
-        if not name:
-            continue
-        try:
-            return ctypes.CDLL(name)
-        except OSError:
-            continue
-    raise OSError("the HDF5 C library (libhdf5.so) was not found; convert the data set to "
-                  ".npz on a machine that has it (see tests/golden/make_mt_ckd.py).")
-
-
 def read_hdf5(path, names=VARIABLES):
     """Reads the named 1-D variables and their grid attributes from a netCDF-4 file."""
-    lib = _hdf5_library()
-    hid = ctypes.c_int64
-    lib.H5open()
-    lib.H5Eset_auto2.argtypes = [hid, ctypes.c_void_p, ctypes.c_void_p]
-    lib.H5Eset_auto2(0, None, None)         # failures are reported through return values
-    lib.H5Fopen.restype = hid
-    lib.H5Fopen.argtypes = [ctypes.c_char_p, ctypes.c_uint, hid]
-    lib.H5Fclose.argtypes = [hid]
-    lib.H5Dopen2.restype = hid
-    lib.H5Dopen2.argtypes = [hid, ctypes.c_char_p, hid]
-    lib.H5Dclose.argtypes = [hid]
-    lib.H5Dget_space.restype = hid
-    lib.H5Dget_space.argtypes = [hid]
-    lib.H5Sclose.argtypes = [hid]
-    lib.H5Sget_simple_extent_npoints.restype = ctypes.c_int64
-    lib.H5Sget_simple_extent_npoints.argtypes = [hid]
-    lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, ctypes.c_void_p]
-    lib.H5Aopen.restype = hid
-    lib.H5Aopen.argtypes = [hid, ctypes.c_char_p, hid]
-    lib.H5Aread.argtypes = [hid, hid, ctypes.c_void_p]
-    lib.H5Aclose.argtypes = [hid]
-    native_double = hid.in_dll(lib, "H5T_NATIVE_DOUBLE_g").value
-
-    handle = lib.H5Fopen(os.fsencode(path), 0, 0)
-    if handle < 0:
-        raise OSError(f"cannot open {path} as HDF5.")
     tables = {}
-    try:
+    with hdf5_reader.File(path) as source:
         for name in names:
-            dataset = lib.H5Dopen2(handle, name.encode(), 0)
-            if dataset < 0:
-                raise KeyError(f"variable {name} not found in {path}.")
-            space = lib.H5Dget_space(dataset)
-            size = lib.H5Sget_simple_extent_npoints(space)
-            lib.H5Sclose(space)
-            data = np.zeros(size, dtype=np.float64)
-            if lib.H5Dread(dataset, native_double, 0, 0, 0, data.ctypes.data) < 0:
-                raise OSError(f"cannot read variable {name} of {path}.")
-            bounds = []
-            for key in ("lower_bound", "upper_bound", "resolution"):
-                attribute = lib.H5Aopen(dataset, f"wavenumber_{key}".encode(), 0)
-                if attribute < 0:
-                    raise KeyError(f"variable {name} has no attribute wavenumber_{key}.")
-                value = ctypes.c_double()
-                lib.H5Aread(attribute, native_double, ctypes.byref(value))
-                lib.H5Aclose(attribute)
-                bounds.append(value.value)
-            lib.H5Dclose(dataset)
-            tables[name] = CoefficientTable(data, *bounds)
-    finally:
-        lib.H5Fclose(handle)
+            bounds = [source.attribute(name, f"wavenumber_{key}")
+                      for key in ("lower_bound", "upper_bound", "resolution")]
+            tables[name] = CoefficientTable(source.array(name).ravel(), *bounds)
     return tables
 
 

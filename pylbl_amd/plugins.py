@@ -7,11 +7,12 @@ The reference fills its dictionaries from the entry points of the distribution n
 inserting itself, which is what ``register`` does (also into pyLBL's own dictionary when
 that package is importable).
 """
+from .arts_crossfit import CrossSection
 from .gas_optics import Gas
 from .mt_ckd import CONTINUA
 
 molecular_lines = {"mi355x": Gas}
-cross_sections = {}
+cross_sections = {"arts_crossfit": CrossSection}
 # Continua: model name -> {"CO2": class, "H2OForeign": class, ...} (plugins.py:24-34).  The
 # MT-CKD model keeps the reference's name, so Spectroscopy's default fills slot 1.
 continua = {"mt_ckd": CONTINUA}

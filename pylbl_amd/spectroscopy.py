@@ -1,6 +1,6 @@
 """Host orchestration: the counterpart of ``Spectroscopy.compute_absorption``
-(pyLBL/spectroscopy.py:144-206) for mechanism slots 0 ("lines") and 1 ("continuum", MT-CKD);
-cross-sections (slot 2) are outside this build's scope and stay zero.
+(pyLBL/spectroscopy.py:144-206) for all three mechanism slots: 0 "lines", 1 "continuum"
+(MT-CKD), 2 "cross_section" (ARTS-crossfit).
 
 What is kept from the reference: constructor keywords and the KeyError for an unknown
 backend name (:88-118); molecule-outer / level-inner semantics with no state carried between
@@ -17,8 +17,8 @@ from collections import namedtuple
 
 import numpy as np
 
-from .errors import AliasNotFoundError, IsotopologuesNotFoundError, TipsDataNotFoundError, \
-                    TransitionsNotFoundError
+from .errors import AliasNotFoundError, CrossSectionNotFoundError, \
+                    IsotopologuesNotFoundError, TipsDataNotFoundError, TransitionsNotFoundError
 from .engine import DeviceSpectra
 from .plugins import continua, cross_sections, molecular_lines
 from .synthetic import grid_arguments
@@ -88,7 +88,8 @@ class Atmosphere(object):
 class MoleculeCache(object):
     """Caches the per-molecule backend objects (pyLBL/spectroscopy.py:32-69): building them
     uploads the molecule's line table and continuum coefficients to HBM once."""
-    def __init__(self, name, lines_database, lines_engine, continua_engine, device):
+    def __init__(self, name, lines_database, lines_engine, continua_engine,
+                 cross_sections_engine, device):
         try:
             self.gas = lines_engine(lines_database, name, device=device)
         except (AliasNotFoundError, IsotopologuesNotFoundError,
@@ -102,6 +103,13 @@ class MoleculeCache(object):
                 self.gas_continua = [continua_engine[x](device=device) for x in names]
             except KeyError:
                 self.gas_continua = None
+        self.cross_section = None
+        if cross_sections_engine is not None and hasattr(lines_database, "arts_crossfit"):
+            try:
+                self.cross_section = cross_sections_engine(
+                    name, lines_database.arts_crossfit(name), device=device)
+            except (AliasNotFoundError, CrossSectionNotFoundError):
+                self.cross_section = None
 
 
 class _Sum(object):
@@ -123,7 +131,8 @@ class _Sum(object):
 
 
 class Spectroscopy(object):
-    """Line-by-line gas optics (lines and MT-CKD continuum mechanisms) on an MI355X.
+    """Line-by-line gas optics (lines, MT-CKD continua, ARTS-crossfit cross-sections) on an
+    MI355X.
 
     Attributes mirror pyLBL/spectroscopy.py:72-86.
     """
@@ -138,7 +147,8 @@ class Spectroscopy(object):
         # None switches the mechanism off; an unknown name is a KeyError (spectroscopy.py:118).
         self.continua_engine = None if continua_backend is None else continua[continua_backend]
         self.cross_sections_backend = cross_sections_backend
-        self.cross_sections_engine = cross_sections.get(cross_sections_backend)  # not built
+        self.cross_sections_engine = None if cross_sections_backend is None \
+            else cross_sections[cross_sections_backend]
         self.cache = {}
         self.device = device
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
@@ -155,14 +165,15 @@ class Spectroscopy(object):
         data = self.cache.get(name)
         if data is None:
             data = MoleculeCache(name, self.lines_database, self.lines_engine,
-                                 self.continua_engine, self.device)
+                                 self.continua_engine, self.cross_sections_engine, self.device)
             self.cache[name] = data
         return data
 
     def compute_absorption(self, output_format="all", remove_pedestal=None,
                            range_policy="reference"):
         """Computes the absorption coefficient [m-1] on the grid for every level and gas of
-        the atmosphere: spectral lines (slot 0) and MT-CKD continua (slot 1).
+        the atmosphere: spectral lines (slot 0), MT-CKD continua (slot 1) and ARTS-crossfit
+        cross-sections (slot 2).
 
         Args:
             output_format: "all" (per gas, per mechanism), "gas" (per gas, mechanisms summed)
@@ -204,10 +215,12 @@ class Spectroscopy(object):
                                             mole_fractions[name][:1], self.grid)
                 gas = None
             continua_here = data.gas_continua or []
-            if gas is None and not continua_here:
+            cross = data.cross_section
+            if gas is None and not continua_here and cross is None:
                 continue
             if engine is None:
-                engine = gas.engine if gas is not None else continua_here[0].engine
+                engine = gas.engine if gas is not None else \
+                    (continua_here[0].engine if continua_here else cross.engine)
             if not in_hbm:
                 # Too large to keep: one host block per mechanism, summed by numpy below.
                 if gas is not None:
@@ -220,14 +233,20 @@ class Spectroscopy(object):
                                                       self.grid)
                     blocks[(name, 1)] = blocks[(name, 1)] + values if (name, 1) in blocks \
                         else values
+                if cross is not None:
+                    blocks[(name, 2)] = cross.absorption_coefficients(
+                        self.grid, temperature, pressure,
+                        volume_mixing_ratio=mole_fractions[name])
                 continue
             if mode == "total":
                 if total is None:
                     total = _Sum(engine, levels, n)
-                lines_sum = continuum_sum = total
+                lines_sum = continuum_sum = cross_sum = total
             elif mode == "gas":
-                lines_sum = continuum_sum = blocks[(name, 0)] = _Sum(engine, levels, n)
+                lines_sum = continuum_sum = cross_sum = blocks[(name, 0)] = _Sum(engine, levels, n)
             else:
+                cross_sum = blocks[(name, 2)] = _Sum(engine, levels, n) if cross is not None \
+                    else None
                 lines_sum = blocks[(name, 0)] = _Sum(engine, levels, n) if gas is not None \
                     else None
                 continuum_sum = blocks[(name, 1)] = _Sum(engine, levels, n) if continua_here \
@@ -242,6 +261,11 @@ class Spectroscopy(object):
                 continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
                                          out=continuum_sum.buffer,
                                          accumulate=continuum_sum.take(), asynchronous=True)
+            if cross is not None:
+                cross.absorption_coefficients(self.grid, temperature, pressure,
+                                              volume_mixing_ratio=mole_fractions[name],
+                                              out=cross_sum.buffer, accumulate=cross_sum.take(),
+                                              asynchronous=True)
         if engine is not None:
             engine.synchronize()
 
@@ -262,17 +286,16 @@ class Spectroscopy(object):
         beta = {}
         for name in self.atmosphere.gases:
             varname = "{}_absorption".format(name)
-            lines, continuum = fetch((name, 0)), fetch((name, 1))
+            lines, continuum, cross = fetch((name, 0)), fetch((name, 1)), fetch((name, 2))
             if mode == "all":
                 values = np.zeros([levels, len(MECHANISMS), columns])
-                if lines is not None:
-                    values[:, 0, :] = lines
-                if continuum is not None:
-                    values[:, 1, :] = continuum
+                for slot, part in enumerate((lines, continuum, cross)):
+                    if part is not None:
+                        values[:, slot, :] = part
                 beta[varname] = values.reshape(self.output.dim_sizes)
             else:
                 values = np.zeros((levels, columns))
-                for part in (lines, continuum):
+                for part in (lines, continuum, cross):
                     if part is not None:
                         values = values + part
                 beta[varname] = values.reshape(shape + [columns])

@@ -151,3 +151,29 @@ def grid_arguments(grid):
     vn = int(round(grid[-1]) + 1)
     n_per_v = int(round(1./(grid[1] - grid[0])))
     return v0, vn, n_per_v
+
+
+def cross_section_bands(seed=0, ranges=((600., 900.), (1050., 1250.)), spacing=0.05):
+    """Synthetic ARTS-crossfit-like bands: [(frequency [Hz], coefficients [4, nfreq]), ...].
+
+    No coefficient file exists offline (the reference downloads them,
+    pyLBL/arts_crossfit/webapi.py).  Frequencies are unevenly spaced; the fit p00 + p10 T +
+    p01 P + p20 T^2 has a smooth two-peak shape of ~1e-22 m2 with small T/P terms and noise
+    that drives it negative in the wings, so the clipping rule
+    (xsec_aux_functions.py:104-119) is exercised.
+    """
+    rng = np.random.default_rng(4000 + seed)
+    bands = []
+    for lower, upper in ranges:
+        size = int((upper - lower)/spacing)
+        steps = rng.uniform(0.5, 1.5, size)
+        wavenumber = lower + (upper - lower)*np.cumsum(steps)/np.sum(steps)
+        f = (wavenumber - lower)/(upper - lower)
+        shape = 1e-22*(np.exp(-((f - 0.4)/0.1)**2) + 0.5*np.exp(-((f - 0.7)/0.05)**2))
+        coefficients = np.zeros((4, size))
+        coefficients[0] = shape + 2e-24*rng.standard_normal(size)
+        coefficients[1] = 1e-26*rng.standard_normal(size)
+        coefficients[2] = 1e-29*rng.standard_normal(size)
+        coefficients[3] = 1e-29*rng.standard_normal(size)
+        bands.append((wavenumber*299792458.0*100, coefficients))
+    return bands
