@@ -62,7 +62,8 @@ def parse():
                         help="only the timed steps: no CPU baseline, no far-field extra pass "
                              "(what scripts/profile_bench.sh runs under rocprofv3)")
     parser.add_argument("--extras", default="all", choices=["all", "none", "farfield", "continuum"],
-                        help="which untimed extra legs run after the timed steps")
+                        help="which untimed extra legs run after the timed steps "
+                             "(continuum = the continuum and cross-section slots)")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; not the default)")
@@ -264,6 +265,57 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
     }
 
 
+def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps):
+    """Times the cross-section kernels (pylbl_amd/csrc/xsec.h) for one halocarbon-like
+    molecule with synthetic coefficient bands (the reference's files are a download) on the
+    workload's grid and levels."""
+    from pylbl_amd import synthetic
+    from pylbl_amd.engine import DeviceSpectra
+    from pylbl_amd.mt_ckd import resident_grid
+    grid = np.arange(v_lo, v_hi, dv)
+    span = v_hi - v_lo
+    ranges = ((v_lo + 0.12*span, v_lo + 0.18*span), (v_lo + 0.21*span, v_lo + 0.25*span))
+    bands = synthetic.cross_section_bands(seed=11, ranges=ranges, spacing=0.03)
+    handle = engine.load_xsec(bands)
+    grid_handle = resident_grid(engine, grid)
+    t, p = atmos.t[mine], atmos.p[mine]
+    vmr = np.full(t.size, 2.3e-10)
+    block = DeviceSpectra(engine, t.size, grid.size)
+
+    def step():
+        engine.xsec_compute(handle, grid_handle, grid.size, t, p, vmr=vmr, out=block,
+                            asynchronous=True)
+    for _ in range(2):
+        step()
+    engine.synchronize()
+    engine.set_option("timing", 1)
+    engine.timing(reset=True)
+    start = time.perf_counter()
+    for _ in range(steps):
+        step()
+    engine.synchronize()
+    elapsed = time.perf_counter() - start
+    kernel_ms, launches = engine.timing(reset=True)
+    engine.set_option("timing", 0)
+    block.free()
+    engine.free_xsec(handle)
+    achieved = 16.*grid.size*t.size/(kernel_ms[7]*1e-3/steps)/1e9
+    return {
+        "workload": f"ARTS-crossfit-like molecule, {len(bands)} bands of "
+                    f"{'+'.join(str(f.size) for f, _ in bands)} frequencies (synthetic), "
+                    f"{t.size} level(s), {grid.size} points, n k written to HBM",
+        "ms_per_step": elapsed/steps*1e3,
+        "spectra_per_s": t.size*steps/elapsed,
+        "kernel_ms_per_step": {"fit": kernel_ms[6]/steps, "interpolate": kernel_ms[7]/steps},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "lbl::xsec_interp_kernel",
+                     "avg_launch_ms": kernel_ms[7]/max(launches[7], 1),
+                     "note": "16 algorithmic bytes per point and level (wavenumber in, n k out); "
+                             "HIP events on the engine's stream"},
+    }
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -432,6 +484,11 @@ def main():
             args.extras in ("all", "continuum"):
         continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps)
 
+    cross_section_extra = None
+    if world == 1 and not args.ablate and not args.host_output and \
+            args.extras in ("all", "continuum"):
+        cross_section_extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps)
+
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
                          device="cpu" if on_host else "cuda")
     if world > 1:
@@ -491,6 +548,12 @@ def main():
         }
         if farfield_extra is not None:
             line["farfield_option"] = farfield_extra
+        if cross_section_extra is not None:
+            line["cross_section_slot"] = cross_section_extra
+            traffic, source = profiled_traffic(line["config"]["workload"], "xsec_interp_kernel")
+            if traffic is not None:
+                cross_section_extra["roofline"]["traffic"] = traffic
+                cross_section_extra["roofline"]["traffic_source"] = f"profiles/{source}"
         if continuum_extra is not None:
             line["continuum_slot"] = continuum_extra
             traffic, source = profiled_traffic(line["config"]["workload"], "continuum_interp_kernel")

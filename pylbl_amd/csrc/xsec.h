@@ -44,26 +44,30 @@ struct XsecLevel
     double density;         // P x /(kb T) [m-3] (spectroscopy.py:18-29), 1 if not scaled
 };
 
+constexpr int kModelThreads = 1024;
+
 __device__ __forceinline__ double block_sum(double value, double * scratch)
 {
-    // 256 threads = 4 wavefronts; fixed order, so the result does not depend on timing.
+    // 16 wavefronts; fixed order, so the result does not depend on timing.
     for (int offset = 32; offset > 0; offset >>= 1) value += __shfl_down(value, offset, 64);
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[wave] = value;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    double total = 0.;
+    for (int w = 0; w < kModelThreads/64; ++w) total += scratch[w];
+    return total;
 }
 
-// grid = (bands, levels), 256 threads.  coeffs: per band [4][size] at 4*offset.
-__global__ __launch_bounds__(256) void xsec_model_kernel(XsecSet set,
+// grid = (bands, levels), kModelThreads threads.  coeffs: per band [4][size] at 4*offset.
+__global__ __launch_bounds__(kModelThreads) void xsec_model_kernel(XsecSet set,
                                                          const double * __restrict__ fgrid,
                                                          const double * __restrict__ coeffs,
                                                          const XsecLevel * __restrict__ levels,
                                                          double * __restrict__ values,
                                                          double * __restrict__ slopes)
 {
-    __shared__ double scratch[4];
+    __shared__ double scratch[kModelThreads/64];
     const XsecBand b = set.band[blockIdx.x];
     const XsecLevel s = levels[blockIdx.y];
     const double * c = coeffs + 4*b.offset;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void xsec_model_kernel(XsecSet set,
     const double * f = fgrid + b.offset;
     const double tt = s.t*s.t;
     double raw_sum = 0., kept_sum = 0., negatives = 0.;
-    for (int j = threadIdx.x; j < b.size; j += 256)
+    for (int j = threadIdx.x; j < b.size; j += kModelThreads)
     {
         // Rows added in the reference's order (xsec_aux_functions.py:49-75).
         const double value = ((c[j]*1. + c[b.size + j]*s.t) + c[2*b.size + j]*s.p) +
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void xsec_model_kernel(XsecSet set,
         // xsec_aux_functions.py:104-119: clip; rescale only when the integral was not negative.
         const double weight = raw_sum >= 0. ? raw_sum/kept_sum : 1.;
         const bool rescale = raw_sum >= 0.;
-        for (int j = threadIdx.x; j < b.size; j += 256)
+        for (int j = threadIdx.x; j < b.size; j += kModelThreads)
         {
             double value = out[j];
             value = value < 0. ? 0. : value;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void xsec_model_kernel(XsecSet set,
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < b.size; j += 256)
+    for (int j = threadIdx.x; j < b.size; j += kModelThreads)
     {
         slope[j] = j + 1 < b.size ? (out[j + 1] - out[j])/(f[j + 1] - f[j]) : 0.;
     }
