@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
     const int level0 = blockIdx.y*LV;
     const int count = min(LV, n_levels - level0);
     // Search window of every band for this workgroup's points: exact when the grid ascends.
-    if (threadIdx.x < set.n_bands)
+    if ((int)threadIdx.x < set.n_bands)
     {
         const XsecBand b = set.band[threadIdx.x];
         int lo = 0, hi = b.size;
