@@ -69,3 +69,30 @@ def test_oracle_interpolation_conventions():
     assert out[0] == 0. and out[-1] == 0. and out[2] != 0.
     single = [xsec_oracle.absorption_coefficient([b], grid, 250., 5e4) for b in bands]
     np.testing.assert_allclose(out, single[0] + single[1], rtol=1e-15)
+
+
+def test_hdf5_coefficient_file(tmp_path):
+    """A netCDF-4/HDF5 file laid out as cross_section.py:29-40 reads it: integer `bands`,
+    `band<m>_fgrid` [nfreq] and `band<m>_coeffs` stored [nfreq, 4]."""
+    from tests import hdf5_writer
+    try:
+        from pylbl_amd import hdf5_reader
+        hdf5_reader.library()
+    except OSError as error:
+        pytest.skip(str(error))
+    bands = synthetic.cross_section_bands(seed=7, ranges=((10., 12.), (30., 31.)), spacing=0.1)
+    path = tmp_path / "CFC12.nc"
+    arrays = {"bands": np.asarray([1, 2], dtype=np.int32)}
+    for m, (frequency, coefficients) in zip((1, 2), bands):
+        arrays[f"band{m}_fgrid"] = frequency
+        arrays[f"band{m}_coeffs"] = np.ascontiguousarray(coefficients.T)
+    hdf5_writer.write(path, arrays)
+    with hdf5_reader.File(path) as source:
+        assert source.has("band1_fgrid") and not source.has("band3_fgrid")
+        assert source.array("band2_coeffs").shape == (bands[1][0].size, 4)
+        with pytest.raises(KeyError):
+            source.array("missing")
+    for (f, c), (f2, c2) in zip(bands, arts_crossfit.read_bands(path)):
+        assert np.array_equal(f, f2) and np.array_equal(c, c2)
+    with pytest.raises(OSError):
+        hdf5_reader.File(tmp_path / "absent.nc")
