@@ -481,14 +481,23 @@ int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & ti
 Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
                           const Tiling & tiling, int points, hipStream_t stream)
 {
-    for (auto & p : m.plans)
+    for (size_t i = 0; i < m.plans.size(); ++i)
     {
+        Molecule::Plan * p = m.plans[i].get();
         if (p->v0 == g.v0 && p->vn == g.vn && p->n_per_v == g.n_per_v &&
             p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned &&
             p->farfield == engine->farfield)
         {
-            return *p;
+            // Most recently used last.
+            std::rotate(m.plans.begin() + i, m.plans.begin() + i + 1, m.plans.end());
+            return *m.plans.back();
         }
+    }
+    // A long-lived process may see many grids: keep the 16 most recent plans per molecule.
+    if (m.plans.size() >= 16)
+    {
+        engine->drain_lanes();      // a queued kernel may still read the oldest plan's items
+        m.plans.erase(m.plans.begin());
     }
     std::unique_ptr<Molecule::Plan> plan(new Molecule::Plan());
     plan->v0 = g.v0; plan->vn = g.vn; plan->n_per_v = g.n_per_v; plan->cut_off = g.cut_off;

@@ -352,3 +352,28 @@ def test_reference_known_answers_if_real_database_present():
     k = k[:grid.size]
     assert np.log(np.max(k)) == pytest.approx(-48.159224953962244)
     assert np.log(np.sum(k)*(grid[1] - grid[0])) == pytest.approx(-46.496121930910135)
+
+
+def test_plan_cache_is_bounded_and_results_do_not_depend_on_it(oracle):
+    """The per-molecule work-item plans are kept for the 16 most recent grids; cycling through
+    more grids than that (asynchronously, so evictions meet queued kernels) changes nothing."""
+    from pylbl_amd.engine import DeviceSpectra, default_engine
+    engine = default_engine(0)
+    table = synthetic.line_table("CO2", 1., 400., num_lines=3000, seed=77)
+    handle = engine.load(table)
+    first = {}
+    for sweep in range(2):
+        for k in range(20):
+            v0, vn, npv = 10 + 5*k, 200 + 5*k, 10
+            out = DeviceSpectra(engine, 1, (vn - v0)*npv)
+            engine.compute(handle, 250., 5e4, 3.6e-4, v0, vn, npv, out=out, asynchronous=True)
+            engine.synchronize()
+            values = out.to_host()[0]
+            out.free()
+            if sweep == 0:
+                first[k] = values
+            else:
+                assert np.array_equal(values, first[k])
+    k_ref, _ = oracle.absorption_port(table, 250., 5e4, 3.6e-4, 10, 200, 10)
+    np.testing.assert_allclose(first[0], k_ref, rtol=1e-6)
+    engine.free(handle)
