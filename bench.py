@@ -546,6 +546,11 @@ def main():
                 "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
                 "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
         }
+        if args.pedestal:
+            line["roofline"]["note"] += ("; remove_pedestal=True: calls alternate between engine "
+                                         "lanes and their accumulate kernels overlap in time, so "
+                                         "avg_launch_ms is not the duration of a kernel running "
+                                         "alone (see the plain run for that)")
         if farfield_extra is not None:
             line["farfield_option"] = farfield_extra
         if cross_section_extra is not None:

@@ -88,7 +88,7 @@ struct RawBuffer
 
 struct PedestalWorkspace
 {
-    RawBuffer<int> block_count;     // [levels][blocks of 1024 rows]
+    RawBuffer<int> block_count;     // [levels][blocks of kScanThreads rows]
     RawBuffer<int> run_start;       // [levels][n_lines]
     RawBuffer<int> run_count;       // [levels]
     RawBuffer<RunMeta> runs;        // [levels][max_runs]
@@ -147,15 +147,20 @@ __device__ __forceinline__ int block_inclusive_scan(int value, int * wave_total,
     return before + scan;
 }
 
-// Pass 1: runs opened inside every block of 1024 rows.
-__global__ __launch_bounds__(1024) void run_count_kernel(const LineWing * __restrict__ wing,
+// The three run-finding kernels use 256-thread workgroups with a handful of registers so that
+// they can be placed beside a resident accumulate grid (which leaves ~56 VGPRs and two wave
+// slots per SIMD free); 1024-thread workgroups had to wait for it to drain.
+constexpr int kScanThreads = 256;
+
+// Pass 1: runs opened inside every block of kScanThreads rows.
+__global__ __launch_bounds__(kScanThreads) void run_count_kernel(const LineWing * __restrict__ wing,
                                                          const int * __restrict__ sorted_of_row,
                                                          long long n_lines, int n_blocks,
                                                          int * __restrict__ block_count)
 {
     __shared__ int wave_total[16];
     const int level = blockIdx.y;
-    const long long r = (long long)blockIdx.x*1024 + threadIdx.x;
+    const long long r = (long long)blockIdx.x*kScanThreads + threadIdx.x;
     const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
     int total;
     block_inclusive_scan(flag, wave_total, total);
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(1024) void run_count_kernel(const LineWing * __rest
 }
 
 // Pass 2 (one block per level): exclusive scan of the block counts, in place.
-__global__ __launch_bounds__(1024) void run_offset_kernel(int n_blocks, int * __restrict__ block_count,
+__global__ __launch_bounds__(kScanThreads) void run_offset_kernel(int n_blocks, int * __restrict__ block_count,
                                                           int * __restrict__ run_count)
 {
     __shared__ int wave_total[16];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(1024) void run_offset_kernel(int n_blocks, int * __
     int * counts = block_count + (long long)blockIdx.x*n_blocks;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024)
+    for (int base = 0; base < n_blocks; base += kScanThreads)
     {
         const int i = base + threadIdx.x;
         const int value = i < n_blocks ? counts[i] : 0;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(1024) void run_offset_kernel(int n_blocks, int * __
 }
 
 // Pass 3: rows that open a run, compacted in row order.
-__global__ __launch_bounds__(1024) void run_compact_kernel(const LineWing * __restrict__ wing,
+__global__ __launch_bounds__(kScanThreads) void run_compact_kernel(const LineWing * __restrict__ wing,
                                                            const int * __restrict__ sorted_of_row,
                                                            long long n_lines, int n_blocks,
                                                            const int * __restrict__ block_offset,
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(1024) void run_compact_kernel(const LineWing * __re
 {
     __shared__ int wave_total[16];
     const int level = blockIdx.y;
-    const long long r = (long long)blockIdx.x*1024 + threadIdx.x;
+    const long long r = (long long)blockIdx.x*kScanThreads + threadIdx.x;
     const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
     int total;
     const int inclusive = block_inclusive_scan(flag, wave_total, total);
@@ -333,8 +338,8 @@ __device__ __forceinline__ double read_lane(double value, int lane)
 
 constexpr int kLinkReach = 64;      // history visible to a run: the previous 64 runs
 
-// prefix_last[r] = max over q <= r of the runs' last slots (one 1024-thread block per level).
-__global__ __launch_bounds__(1024) void run_prefix_kernel(const int * __restrict__ run_count,
+// prefix_last[r] = max over q <= r of the runs' last slots (one workgroup per level).
+__global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __restrict__ run_count,
                                                           int max_runs,
                                                           const RunMeta * __restrict__ runs,
                                                           int * __restrict__ prefix_last)
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(1024) void run_prefix_kernel(const int * __restrict
     int * out = prefix_last + (long long)level*max_runs;
     if (threadIdx.x == 0) carry = -1;
     __syncthreads();
-    for (int base = 0; base < count; base += 1024)
+    for (int base = 0; base < count; base += kScanThreads)
     {
         const int r = base + threadIdx.x;
         int value = r < count ? meta[r].last_slot : -1;
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(1024) void run_prefix_kernel(const int * __restrict
         value = max(value, before);
         if (r < count) out[r] = value;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = value;
+        if (threadIdx.x == kScanThreads - 1) carry = value;
         __syncthreads();
     }
 }
@@ -817,22 +822,22 @@ inline void pedestal_check(hipError_t status, const char * what)
 }
 
 // First half: finds the runs (three short scan kernels) and starts the copy of the run
-// counts to the host.  Their 1024-thread workgroups cannot be placed while an accumulate
-// grid fills the chip, so the engine orders them before the accumulate launch.
+// counts to the host.  The engine orders them before the accumulate launch of the same call
+// (a resident accumulate grid of another call does not hold them up, see kScanThreads).
 inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                                const LineWing * wing, int count)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
-    const int n_blocks = (int)((n_lines + 1023)/1024);
+    const int n_blocks = (int)((n_lines + kScanThreads - 1)/kScanThreads);
     ws.block_count.reserve((size_t)count*n_blocks);
     ws.run_start.reserve((size_t)(count*n_lines));
     ws.run_count.reserve((size_t)count);
-    hipLaunchKernelGGL(run_count_kernel, dim3(n_blocks, count), dim3(1024), 0, stream, wing,
+    hipLaunchKernelGGL(run_count_kernel, dim3(n_blocks, count), dim3(kScanThreads), 0, stream, wing,
                        t.sorted_of_row, n_lines, n_blocks, ws.block_count.data);
-    hipLaunchKernelGGL(run_offset_kernel, dim3(count), dim3(1024), 0, stream, n_blocks,
+    hipLaunchKernelGGL(run_offset_kernel, dim3(count), dim3(kScanThreads), 0, stream, n_blocks,
                        ws.block_count.data, ws.run_count.data);
-    hipLaunchKernelGGL(run_compact_kernel, dim3(n_blocks, count), dim3(1024), 0, stream, wing,
+    hipLaunchKernelGGL(run_compact_kernel, dim3(n_blocks, count), dim3(kScanThreads), 0, stream, wing,
                        t.sorted_of_row, n_lines, n_blocks, ws.block_count.data,
                        ws.run_start.data);
     check(hipGetLastError(), "run scan kernels");
@@ -875,7 +880,7 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         hipLaunchKernelGGL(fill_int_kernel, dim3((count + 255)/256), dim3(256), 0, stream,
                            ws.regular.data, count, 1);
         ws.prefix_last.reserve((size_t)count*max_runs);
-        hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(1024), 0, stream,
+        hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
                            ws.run_count.data, max_runs, ws.runs.data, ws.prefix_last.data);
         hipLaunchKernelGGL(run_links_kernel, dim3((max_runs + 255)/256, count), dim3(256), 0,
                            stream, ws.run_count.data, max_runs, slot_stride, ws.runs.data,
