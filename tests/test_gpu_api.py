@@ -354,6 +354,22 @@ def test_reference_known_answers_if_real_database_present():
     assert np.log(np.sum(k)*(grid[1] - grid[0])) == pytest.approx(-46.496121930910135)
 
 
+def test_reference_end_to_end_known_answer_if_real_database_present():
+    """The reference's end-to-end test (tests/test_spectroscopy.py:15-25): total absorption
+    of the single-layer atmosphere (8 gases; lines + continua + cross-sections) on
+    arange(1, 3000, 1).  Needs the real database and the cross-section files it points to."""
+    import os
+    path = os.environ.get("PYLBL_DATABASE")
+    if not path or not os.path.isfile(path):
+        pytest.skip("no real pyLBL database available ($PYLBL_DATABASE)")
+    from pylbl_amd import Spectroscopy
+    grid = np.arange(1., 3000., 1.)
+    spec = Spectroscopy(synthetic.surface_level(), grid, Database(path))
+    total = np.asarray(spec.compute_absorption(output_format="total")["absorption"])
+    assert np.max(total) == pytest.approx(154.77712952851365)
+    assert np.log(np.sum(total)) == pytest.approx(7.212513759327571)
+
+
 def test_plan_cache_is_bounded_and_results_do_not_depend_on_it(oracle):
     """The per-molecule work-item plans are kept for the 16 most recent grids; cycling through
     more grids than that (asynchronously, so evictions meet queued kernels) changes nothing."""
