@@ -112,6 +112,19 @@ void *lbl_stream(lbl_engine *engine);
 int lbl_device_alloc(lbl_engine *engine, int64_t bytes, void **pointer);
 int lbl_device_free(lbl_engine *engine, void *pointer);
 int lbl_copy_to_host(lbl_engine *engine, void *host, const void *device, int64_t bytes);
+/* `rows` rows of `row_bytes` bytes from device memory (row pitch device_pitch bytes) into host
+ * memory (row pitch host_pitch bytes): lets a host place the first grid.size columns of every
+ * level straight into its final array, e.g. beta[level, mechanism, :]
+ * (pyLBL/spectroscopy.py:188-191), without an intermediate copy.  Without LBL_ASYNC it returns
+ * when the rows have arrived. */
+int lbl_copy_rows_to_host(lbl_engine *engine, void *host, int64_t host_pitch,
+                          const void *device, int64_t device_pitch, int64_t row_bytes,
+                          int64_t rows, int32_t flags);
+/* Page-locked host memory for results: copies into it run at the full rate of the host link and,
+ * with LBL_ASYNC in lbl_copy_rows_to_host, beside the kernels queued after them (the copy waits
+ * for everything queued before it on any lane; lbl_synchronize waits for the copy). */
+int lbl_host_alloc(lbl_engine *engine, int64_t bytes, void **pointer);
+int lbl_host_free(lbl_engine *engine, void *pointer);
 
 /* Debug/inspection: per-line scalars for one level as the engine computed them, in
  * reference row order: n_lines x 8 doubles {centre, doppler hwhm, lorentz hwhm, strength,

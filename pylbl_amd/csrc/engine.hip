@@ -138,6 +138,7 @@ struct Lane
     hipStream_t side = nullptr;     // the pedestal pre-pass
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
     hipEvent_t runs_found = nullptr;
+    hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
     bool levels_in_flight = false;
     DeviceBuffer<LineWing> wing;
     DeviceBuffer<LineCore> core;
@@ -163,6 +164,7 @@ struct Lane
         HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
     }
@@ -179,6 +181,7 @@ struct Lane
         if (prepared != nullptr) (void)hipEventDestroy(prepared);
         if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
         if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
+        if (queued != nullptr) (void)hipEventDestroy(queued);
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
         if (side != nullptr) (void)hipStreamDestroy(side);
@@ -275,6 +278,7 @@ struct lbl_engine
 {
     int device = 0;
     hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
+    hipStream_t copy_stream = nullptr;  // results on their way to host memory
     std::string error;
     std::vector<std::unique_ptr<Molecule>> molecules;
     std::vector<std::unique_ptr<ContinuumSet>> continua;
@@ -349,6 +353,7 @@ struct lbl_engine
     void drain_lanes()
     {
         for (auto & lane : lanes) lane.drain();
+        if (copy_stream != nullptr) (void)hipStreamSynchronize(copy_stream);
     }
 };
 
@@ -976,6 +981,7 @@ int lbl_engine_create(int device, lbl_engine ** engine)
         e->device = device;
         for (auto & lane : e->lanes) lane.create();
         e->stream = e->lanes[0].main;
+        HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         *engine = e.release();
     }
     catch (const HipFailure & f)
@@ -1001,6 +1007,7 @@ int lbl_engine_destroy(lbl_engine * engine)
     engine->xsecs.clear();
     engine->grids.clear();
     for (auto & lane : engine->lanes) lane.destroy();
+    if (engine->copy_stream != nullptr) (void)hipStreamDestroy(engine->copy_stream);
     delete engine;
     return LBL_OK;
 }
@@ -1156,6 +1163,8 @@ int lbl_synchronize(lbl_engine * engine)
         if (status == hipSuccess) status = hipStreamSynchronize(lane.side);
         if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
     }
+    const hipError_t status = hipStreamSynchronize(engine->copy_stream);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
     return LBL_OK;
 }
 
@@ -1271,6 +1280,58 @@ int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int6
     hipError_t status = hipMemcpyAsync(host, device, (size_t)bytes, hipMemcpyDeviceToHost,
                                        engine->stream);
     if (status == hipSuccess) status = hipStreamSynchronize(engine->stream);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_copy_rows_to_host(lbl_engine * engine, void * host, int64_t host_pitch,
+                          const void * device, int64_t device_pitch, int64_t row_bytes,
+                          int64_t rows, int32_t flags)
+{
+    if (engine == nullptr || host == nullptr || device == nullptr || row_bytes < 0 || rows < 0 ||
+        host_pitch < row_bytes || device_pitch < row_bytes)
+    {
+        return LBL_BAD_ARGUMENT;
+    }
+    if (rows == 0 || row_bytes == 0) return LBL_OK;
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        // The rows may have been written on any lane: the copy stream waits for what each of
+        // them holds now, then copies beside whatever is queued afterwards.
+        for (auto & lane : engine->lanes)
+        {
+            HIP_TRY(hipEventRecord(lane.queued, lane.main));
+            HIP_TRY(hipStreamWaitEvent(engine->copy_stream, lane.queued, 0));
+        }
+        HIP_TRY(hipMemcpy2DAsync(host, (size_t)host_pitch, device, (size_t)device_pitch,
+                                 (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToHost,
+                                 engine->copy_stream));
+        if (!(flags & LBL_ASYNC)) HIP_TRY(hipStreamSynchronize(engine->copy_stream));
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    return LBL_OK;
+}
+
+int lbl_host_alloc(lbl_engine * engine, int64_t bytes, void ** pointer)
+{
+    if (engine == nullptr || pointer == nullptr || bytes < 0) return LBL_BAD_ARGUMENT;
+    (void)hipSetDevice(engine->device);
+    hipError_t status = hipHostMalloc(pointer, (size_t)std::max<int64_t>(bytes, 8),
+                                      hipHostMallocDefault);
+    if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_host_free(lbl_engine * engine, void * pointer)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    (void)hipSetDevice(engine->device);
+    if (engine->copy_stream != nullptr) (void)hipStreamSynchronize(engine->copy_stream);
+    hipError_t status = hipHostFree(pointer);
     if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
     return LBL_OK;
 }

@@ -7,6 +7,7 @@ library is missing or no MI355X is visible, creating an Engine raises.
 from ctypes import CDLL, POINTER, Structure, byref, c_char_p, c_double, c_int32, c_int64, \
                    c_void_p
 from pathlib import Path
+import weakref
 
 import numpy as np
 
@@ -25,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
     "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
+    "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
     "lbl_line_scalars", "lbl_absorption", "lbl_version",
     "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
     "lbl_continuum_compute", "lbl_continuum_bands",
@@ -77,6 +79,10 @@ def library():
     lib.lbl_device_alloc.argtypes = [c_void_p, c_int64, POINTER(c_void_p)]
     lib.lbl_device_free.argtypes = [c_void_p, c_void_p]
     lib.lbl_copy_to_host.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
+    lib.lbl_copy_rows_to_host.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                          c_int64, c_int64, c_int32]
+    lib.lbl_host_alloc.argtypes = [c_void_p, c_int64, POINTER(c_void_p)]
+    lib.lbl_host_free.argtypes = [c_void_p, c_void_p]
     lib.lbl_line_scalars.argtypes = [c_void_p, c_int32] + [c_double]*3 + [c_int32]*6 + [c_void_p]
     lib.lbl_absorption.argtypes = [c_double]*3 + [c_int32]*3 + [c_void_p, c_char_p, c_char_p,
                                   c_int32, c_int32]
@@ -121,6 +127,23 @@ class DeviceSpectra(object):
             self.engine.handle, out.ctypes.data, self.pointer, out.nbytes))
         return out
 
+    def to_host_into(self, target, columns=None, asynchronous=False):
+        """Copies the first `columns` values of every row straight into `target`, a float64
+        array view [rows, columns] whose rows are contiguous (any row stride), e.g.
+        beta[:, mechanism, :].  asynchronous: queue the copy behind everything queued so far
+        and return; Engine.synchronize() waits for it (use page-locked targets,
+        Engine.host_array, or the copy blocks anyway)."""
+        columns = self.shape[1] if columns is None else int(columns)
+        if target.dtype != np.float64 or target.shape != (self.shape[0], columns) or \
+                columns > self.shape[1] or (columns > 1 and target.strides[1] != 8) or \
+                (self.shape[0] > 1 and target.strides[0] < columns*8):
+            raise ValueError("target must be float64[rows, columns] with contiguous rows.")
+        pitch = target.strides[0] if self.shape[0] > 1 else columns*8
+        self.engine._check(self.engine.lib.lbl_copy_rows_to_host(
+            self.engine.handle, target.ctypes.data, pitch, self.pointer, self.shape[1]*8,
+            columns*8, self.shape[0], ASYNC if asynchronous else 0))
+        return target
+
     def free(self):
         if self.pointer:
             self.engine.lib.lbl_device_free(self.engine.handle, self.pointer)
@@ -131,6 +154,58 @@ class DeviceSpectra(object):
             self.free()
         except Exception:
             pass
+
+
+class PinnedPool(object):
+    """Page-locked host arrays for results.  Pinning memory is slow, so buffers are recycled:
+    when the last view of an array handed out here is garbage-collected its buffer goes back
+    to the pool (up to `limit` bytes of idle buffers are kept)."""
+    def __init__(self, engine, limit=8 << 30):
+        self.engine = weakref.ref(engine)
+        self.limit = limit
+        self.idle = []          # (capacity, pointer)
+        self.idle_bytes = 0
+
+    def array(self, shape):
+        shape = tuple(int(x) for x in shape)
+        count = int(np.prod(shape)) if shape else 1
+        nbytes = max(count*8, 8)
+        engine = self.engine()
+        best = None
+        for i, (capacity, _) in enumerate(self.idle):
+            if nbytes <= capacity <= 2*nbytes + (1 << 20) and \
+                    (best is None or capacity < self.idle[best][0]):
+                best = i
+        if best is not None:
+            capacity, pointer = self.idle.pop(best)
+            self.idle_bytes -= capacity
+        else:
+            capacity, handle = nbytes, c_void_p()
+            engine._check(engine.lib.lbl_host_alloc(engine.handle, capacity, byref(handle)))
+            pointer = handle.value
+        from ctypes import c_char
+        buffer = (c_char*capacity).from_address(pointer)
+        weakref.finalize(buffer, PinnedPool._release, weakref.ref(self), capacity, pointer)
+        return np.frombuffer(buffer, dtype=np.float64, count=count).reshape(shape)
+
+    @staticmethod
+    def _release(pool, capacity, pointer):
+        pool = pool()
+        engine = pool.engine() if pool is not None else None
+        if engine is None or not engine.handle:
+            return                      # engine gone: the runtime reclaims the pages at exit
+        if pool.idle_bytes + capacity <= pool.limit:
+            pool.idle.append((capacity, pointer))
+            pool.idle_bytes += capacity
+        else:
+            engine.lib.lbl_host_free(engine.handle, c_void_p(pointer))
+
+    def clear(self):
+        engine = self.engine()
+        for _, pointer in self.idle:
+            if engine is not None and engine.handle:
+                engine.lib.lbl_host_free(engine.handle, c_void_p(pointer))
+        self.idle, self.idle_bytes = [], 0
 
 
 class Engine(object):
@@ -144,6 +219,12 @@ class Engine(object):
             self.handle = c_void_p()
             raise EngineError(f"lbl_engine_create failed ({status}): {message}")
         self.device = int(device)
+        self.pinned = PinnedPool(self)
+
+    def host_array(self, shape):
+        """float64 array of the given shape in page-locked host memory (recycled, see
+        PinnedPool): the place to receive spectra from HBM."""
+        return self.pinned.array(shape)
 
     def _check(self, status):
         if status != LBL_OK:
@@ -151,6 +232,7 @@ class Engine(object):
 
     def close(self):
         if self.handle:
+            self.pinned.clear()
             self.lib.lbl_engine_destroy(self.handle)
             self.handle = c_void_p()
 

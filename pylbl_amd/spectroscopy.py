@@ -124,10 +124,12 @@ class _Sum(object):
         written, self.written = self.written, True
         return written
 
-    def to_host(self, columns):
-        values = np.ascontiguousarray(self.buffer.to_host()[:, :columns])
-        self.buffer.free()
-        return values
+    def into(self, target):
+        """Queues the copy of the first target.shape[1] columns of every level straight into
+        `target` (a [levels, columns] view with contiguous rows, page-locked); it runs behind
+        the kernels queued so far and beside those queued later."""
+        self.buffer.to_host_into(target, target.shape[1], asynchronous=True)
+        return self
 
 
 class Spectroscopy(object):
@@ -204,7 +206,9 @@ class Spectroscopy(object):
         # Queue every kernel before waiting: one batched call per (molecule, mechanism) for
         # all levels, n*k applied in the kernel epilogue, spectra left in HBM until the end;
         # the sums over mechanisms ("gas") and over gases ("total") happen on the device.
-        blocks = {}             # (gas, mechanism) -> _Sum or host array
+        blocks = {}             # (gas, mechanism) -> host array (only when too large for HBM)
+        results = {}            # gas -> its finished array, being filled by queued copies
+        in_flight = []          # blocks in HBM to release once everything has arrived
         total = None
         for name in self.atmosphere.gases:
             data = self._molecule(name)
@@ -243,14 +247,11 @@ class Spectroscopy(object):
                     total = _Sum(engine, levels, n)
                 lines_sum = continuum_sum = cross_sum = total
             elif mode == "gas":
-                lines_sum = continuum_sum = cross_sum = blocks[(name, 0)] = _Sum(engine, levels, n)
+                lines_sum = continuum_sum = cross_sum = _Sum(engine, levels, n)
             else:
-                cross_sum = blocks[(name, 2)] = _Sum(engine, levels, n) if cross is not None \
-                    else None
-                lines_sum = blocks[(name, 0)] = _Sum(engine, levels, n) if gas is not None \
-                    else None
-                continuum_sum = blocks[(name, 1)] = _Sum(engine, levels, n) if continua_here \
-                    else None
+                cross_sum = _Sum(engine, levels, n) if cross is not None else None
+                lines_sum = _Sum(engine, levels, n) if gas is not None else None
+                continuum_sum = _Sum(engine, levels, n) if continua_here else None
             if gas is not None:
                 gas.absorption_coefficients(
                     temperature, pressure, mole_fractions[name], self.grid,
@@ -266,38 +267,52 @@ class Spectroscopy(object):
                                               volume_mixing_ratio=mole_fractions[name],
                                               out=cross_sum.buffer, accumulate=cross_sum.take(),
                                               asynchronous=True)
+            # This gas's blocks go home while the next gas computes: one copy per block, from
+            # HBM straight into its place in a page-locked result.
+            if mode == "all":
+                values = engine.host_array([levels, len(MECHANISMS), columns])
+                for slot, block in enumerate((lines_sum, continuum_sum, cross_sum)):
+                    if block is None:
+                        values[:, slot, :] = 0.
+                    else:
+                        in_flight.append(block.into(values[:, slot, :]))
+                results[name] = values
+            elif mode == "gas":
+                results[name] = engine.host_array((levels, columns))
+                in_flight.append(lines_sum.into(results[name]))
+        if mode == "total" and total is not None:
+            results["total"] = engine.host_array((levels, columns))
+            in_flight.append(total.into(results["total"]))
         if engine is not None:
             engine.synchronize()
-
-        def fetch(key):
-            block = blocks.get(key)
-            if block is None:
-                return None
-            return block.to_host(columns) if isinstance(block, _Sum) else block
+        for block in in_flight:
+            block.buffer.free()
 
         if mode == "total":
-            values = np.zeros((levels, columns))
-            if total is not None:
-                values = total.to_host(columns)
+            values = results.get("total")
+            if values is None:
+                values = np.zeros((levels, columns))
             for block in blocks.values():           # host blocks of the too-large case
-                values = values + block
+                values += block
             return self._create_output_dataset(
                 {"total": values.reshape(shape + [columns])}, output_format)
         beta = {}
         for name in self.atmosphere.gases:
             varname = "{}_absorption".format(name)
-            lines, continuum, cross = fetch((name, 0)), fetch((name, 1)), fetch((name, 2))
+            values = results.get(name)
             if mode == "all":
-                values = np.zeros([levels, len(MECHANISMS), columns])
-                for slot, part in enumerate((lines, continuum, cross)):
-                    if part is not None:
-                        values[:, slot, :] = part
+                if values is None:
+                    values = np.zeros([levels, len(MECHANISMS), columns])
+                    for slot in range(len(MECHANISMS)):
+                        if (name, slot) in blocks:
+                            values[:, slot, :] = blocks[(name, slot)]
                 beta[varname] = values.reshape(self.output.dim_sizes)
             else:
-                values = np.zeros((levels, columns))
-                for part in (lines, continuum, cross):
-                    if part is not None:
-                        values = values + part
+                if values is None:
+                    values = np.zeros((levels, columns))
+                    for slot in range(len(MECHANISMS)):
+                        if (name, slot) in blocks:
+                            values += blocks[(name, slot)]
                 beta[varname] = values.reshape(shape + [columns])
         return self._create_output_dataset(beta, output_format)
 
@@ -312,7 +327,9 @@ class Spectroscopy(object):
             extra = {}
         else:
             dims.pop(-2)
-            variables = {"absorption": sum(absorption.values())} if absorption else {}
+            parts = list(absorption.values())
+            variables = {"absorption": parts[0] if len(parts) == 1 else sum(parts)} \
+                if parts else {}
             extra = {}
         try:
             from xarray import DataArray, Dataset

@@ -393,3 +393,40 @@ def test_plan_cache_is_bounded_and_results_do_not_depend_on_it(oracle):
     k_ref, _ = oracle.absorption_port(table, 250., 5e4, 3.6e-4, 10, 200, 10)
     np.testing.assert_allclose(first[0], k_ref, rtol=1e-6)
     engine.free(handle)
+
+
+def test_row_copies_and_pinned_results():
+    """lbl_copy_rows_to_host places device rows straight into a strided destination
+    (beta[level, mechanism, :]); page-locked result arrays are recycled once dropped."""
+    import gc
+    from pylbl_amd.engine import DeviceSpectra, default_engine
+    engine = default_engine(0)
+    table = synthetic.line_table("CO2", 1., 60., num_lines=300, seed=5)
+    handle = engine.load(table)
+    levels, v0, vn, npv = 3, 1, 41, 10
+    n, columns = (vn - v0)*npv, 391
+    block = DeviceSpectra(engine, levels, n)
+    t, p, x = [250., 260., 270.], [5e4, 6e4, 7e4], [3e-4, 3e-4, 3e-4]
+    engine.compute(handle, t, p, x, v0, vn, npv, out=block)
+    dense = block.to_host()
+    beta = engine.host_array([levels, 3, columns])
+    beta[...] = -1.
+    block.to_host_into(beta[:, 1, :], columns, asynchronous=True)
+    engine.synchronize()
+    assert np.array_equal(beta[:, 1, :], dense[:, :columns])
+    assert np.all(beta[:, 0, :] == -1.) and np.all(beta[:, 2, :] == -1.)
+    pageable = np.zeros((levels, columns))
+    block.to_host_into(pageable, columns)
+    assert np.array_equal(pageable, dense[:, :columns])
+    with pytest.raises(ValueError):
+        block.to_host_into(np.zeros((levels, columns + 1))[:, ::2], (columns + 1)//2)
+    # Recycling: the buffer of a dropped array is handed out again.
+    address = beta.ctypes.data
+    del beta
+    gc.collect()
+    assert address in [pointer for _, pointer in engine.pinned.idle]
+    idle = len(engine.pinned.idle)
+    again = engine.host_array([levels, 3, columns])
+    assert len(engine.pinned.idle) == idle - 1 and again.shape == (levels, 3, columns)
+    block.free()
+    engine.free(handle)
