@@ -284,7 +284,8 @@ class Engine(object):
             pointer, flags = out.pointer, flags | OUT_DEVICE
         else:
             if out is None:
-                out = np.zeros((t.size, max(n, 0)), dtype=np.float64)
+                # Page-locked and recycled: the copy back runs at the rate of the host link.
+                out = self.host_array((t.size, max(n, 0)))
             if out.shape != (t.size, n) or out.dtype != np.float64 or \
                     not out.flags["C_CONTIGUOUS"]:
                 raise ValueError("out must be C-contiguous float64[levels, n].")
@@ -371,7 +372,7 @@ class Engine(object):
     def _output(self, out, levels, n, flags):
         """(array or DeviceSpectra, pointer, flags, row stride) for a [levels, >= n] block."""
         if out is None:
-            out = np.zeros((levels, n), dtype=np.float64)
+            out = self.host_array((levels, n))
         # Rows may be longer than the grid (the lines path pads them to whole wavenumbers).
         if len(out.shape) != 2 or out.shape[0] != levels or out.shape[1] < n:
             raise ValueError(f"out has shape {out.shape}, need ({levels}, >= {n}).")

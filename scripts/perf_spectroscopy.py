@@ -32,6 +32,15 @@ with tempfile.TemporaryDirectory() as directory:
     spec = Spectroscopy(synthetic.Atmos(p=atmos.p, t=atmos.t,
                                         vmr={k: atmos.vmr[k] for k in formulae}),
                         grid, Database(path))
+    gas = spec._molecule("CO2").gas
+    for _ in range(2):
+        gas.absorption_coefficient(atmos.t[0], atmos.p[0], atmos.vmr["CO2"][0], grid)
+    start = time.perf_counter()
+    for _ in range(5):
+        k = gas.absorption_coefficient(atmos.t[0], atmos.p[0], atmos.vmr["CO2"][0], grid)
+    print(f"Gas.absorption_coefficient (CO2, one level, result on the host): "
+          f"{(time.perf_counter() - start)/5*1e3:.1f} ms per call", flush=True)
+    del k
     for output_format in ("total", "gas", "all"):
         spec.compute_absorption(output_format=output_format)       # warm-up: uploads, plans
         start = time.perf_counter()
