@@ -286,6 +286,8 @@ class Engine(object):
             if out is None:
                 # Page-locked and recycled: the copy back runs at the rate of the host link.
                 out = self.host_array((t.size, max(n, 0)))
+                if accumulate:
+                    out[...] = 0.
             if out.shape != (t.size, n) or out.dtype != np.float64 or \
                     not out.flags["C_CONTIGUOUS"]:
                 raise ValueError("out must be C-contiguous float64[levels, n].")
@@ -373,6 +375,8 @@ class Engine(object):
         """(array or DeviceSpectra, pointer, flags, row stride) for a [levels, >= n] block."""
         if out is None:
             out = self.host_array((levels, n))
+            if flags & ACCUMULATE:
+                out[...] = 0.
         # Rows may be longer than the grid (the lines path pads them to whole wavenumbers).
         if len(out.shape) != 2 or out.shape[0] != levels or out.shape[1] < n:
             raise ValueError(f"out has shape {out.shape}, need ({levels}, >= {n}).")
