@@ -390,7 +390,9 @@ def main():
             self.pointer = tensor.data_ptr()
             self.shape = tuple(tensor.shape)
 
-    host_spectra = np.empty((len(molecules), levels_local, n)) if args.host_output else None
+    # --host-output: page-locked host memory, what Gas/Spectroscopy hand their callers.
+    host_spectra = engine.host_array((len(molecules), levels_local, n)) if args.host_output \
+        else None
 
     def settle(which):
         """Waits for the gather that last used buffer `which`."""
