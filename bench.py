@@ -202,7 +202,7 @@ def cpu_baseline_parallel(tables, atmos, v0, n_per_v, sample_cm, workers):
                       f"units, {evals:.4g} evals in {seconds:.2f} s"}
 
 
-def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
+def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
     """Times the continuum kernels (pylbl_amd/csrc/continuum.h) for the gases of the workload
     that have an MT-CKD continuum.  Needs the coefficient tables ($PYLBL_MT_CKD, an installed
     pyLBL, or the fixture under tests/golden); returns None without them."""
@@ -246,6 +246,22 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
     block.free()
     # Algorithmic bytes per launch: wavenumber in + extinction out per point and level, plus
     # the extinction read back by the launches that add to it.
+    # cpu_baseline of this leg: the numpy restatement of the reference's path (oracle/, "port";
+    # the reference itself needs netCDF4/xarray) for the first level, one thread.
+    cpu = None
+    if with_cpu:
+        from oracle import mt_ckd_oracle
+        tables = mt_ckd_oracle.load_tables(path)
+        first = {formula: values[0] for formula, values in vmr.items()}
+        checkers = [mt_ckd_oracle.Continuum(owner, tables) for owner in owners]
+        begin = time.perf_counter()
+        for checker in checkers:
+            checker.spectra(t[0], p[0], first, grid)
+        seconds = time.perf_counter() - begin
+        cpu = {"value": len(owners)*grid.size/seconds, "unit": "continuum x grid points/s",
+               "cores": 1, "kind": "port",
+               "sample": f"{'+'.join(owners)} for one level on the same {grid.size} points "
+                         f"({seconds:.2f} s)"}
     adding = len(continua) - 1
     bytes_per_step = grid.size*t.size*(16*len(continua) + 8*adding)
     interp_seconds = kernel_ms[5]*1e-3/steps
@@ -255,6 +271,8 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
                     f"in HBM, {t.size} level(s), {grid.size} points",
         "ms_per_step": elapsed/steps*1e3,
         "spectra_per_s": t.size*steps/elapsed,
+        "value": len(owners)*grid.size*t.size*steps/elapsed, "unit": "continuum x grid points/s",
+        "cpu_baseline": cpu,
         "kernel_ms_per_step": {"band_spectra": kernel_ms[4]/steps, "interpolate": kernel_ms[5]/steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved/HBM_PEAK_GBS, "traffic": None,
@@ -265,7 +283,7 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps):
     }
 
 
-def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps):
+def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
     """Times the cross-section kernels (pylbl_amd/csrc/xsec.h) for one halocarbon-like
     molecule with synthetic coefficient bands (the reference's files are a download) on the
     workload's grid and levels."""
@@ -299,6 +317,15 @@ def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps):
     engine.set_option("timing", 0)
     block.free()
     engine.free_xsec(handle)
+    cpu = None
+    if with_cpu:
+        # The reference's fit restated + the scipy interp1d it calls (oracle/, "port").
+        from oracle import xsec_oracle
+        begin = time.perf_counter()
+        xsec_oracle.absorption_coefficient(bands, grid, t[0], p[0])
+        seconds = time.perf_counter() - begin
+        cpu = {"value": grid.size/seconds, "unit": "grid points/s", "cores": 1, "kind": "port",
+               "sample": f"one level on the same {grid.size} points ({seconds:.2f} s)"}
     achieved = 16.*grid.size*t.size/(kernel_ms[7]*1e-3/steps)/1e9
     return {
         "workload": f"ARTS-crossfit-like molecule, {len(bands)} bands of "
@@ -306,6 +333,8 @@ def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps):
                     f"{t.size} level(s), {grid.size} points, n k written to HBM",
         "ms_per_step": elapsed/steps*1e3,
         "spectra_per_s": t.size*steps/elapsed,
+        "value": grid.size*t.size*steps/elapsed, "unit": "grid points/s",
+        "cpu_baseline": cpu,
         "kernel_ms_per_step": {"fit": kernel_ms[6]/steps, "interpolate": kernel_ms[7]/steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved/HBM_PEAK_GBS, "traffic": None,
@@ -484,12 +513,14 @@ def main():
     continuum_extra = None
     if world == 1 and not args.ablate and not args.host_output and \
             args.extras in ("all", "continuum"):
-        continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps)
+        continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps,
+                                        not args.no_cpu_baseline)
 
     cross_section_extra = None
     if world == 1 and not args.ablate and not args.host_output and \
             args.extras in ("all", "continuum"):
-        cross_section_extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps)
+        cross_section_extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps,
+                                                not args.no_cpu_baseline)
 
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
                          device="cpu" if on_host else "cuda")
