@@ -219,8 +219,54 @@ __global__ __launch_bounds__(256) void band_spectra_kernel(BandSet set,
     slopes[at] = slope;
 }
 
-// continuum_interp_kernel<PT, LV>: PT points per thread (256 apart: coalesced 8 B accesses)
+// continuum_interp_kernel<PT, LV>: PT points per thread (pairs of neighbours, 16 B accesses)
 // for LV levels.
+
+// PT values of one thread from / to a row of n doubles: neighbouring pairs move as one
+// 16-byte access when the row is 16-byte aligned (the pair index is even by construction).
+template <int PT, typename Index>
+__device__ __forceinline__ void load_points(const double * __restrict__ row, long long n,
+                                            const Index & index, double (&value)[PT], double fill)
+{
+    const bool aligned = ((unsigned long long)row & 15ull) == 0ull;
+#pragma unroll
+    for (int p = 0; p < PT; p += 2)
+    {
+        const long long i = index(p);
+        if (PT > 1 && aligned && i + 1 < n)
+        {
+            const double2 pair = *reinterpret_cast<const double2 *>(row + i);
+            value[p] = pair.x;
+            if (p + 1 < PT) value[p + 1] = pair.y;
+        }
+        else
+        {
+            value[p] = i < n ? row[i] : fill;
+            if (p + 1 < PT) value[p + 1] = index(p + 1) < n ? row[index(p + 1)] : fill;
+        }
+    }
+}
+
+template <int PT, typename Index>
+__device__ __forceinline__ void store_points(double * __restrict__ row, long long n,
+                                             const Index & index, const double (&value)[PT])
+{
+    const bool aligned = ((unsigned long long)row & 15ull) == 0ull;
+#pragma unroll
+    for (int p = 0; p < PT; p += 2)
+    {
+        const long long i = index(p);
+        if (PT > 1 && aligned && i + 1 < n)
+        {
+            *reinterpret_cast<double2 *>(row + i) = double2{value[p], p + 1 < PT ? value[p + 1] : 0.};
+        }
+        else
+        {
+            if (i < n) row[i] = value[p];
+            if (p + 1 < PT && index(p + 1) < n) row[index(p + 1)] = value[p + 1];
+        }
+    }
+}
 
 // numpy.interp(x, xp, fp, left=0, right=0) for every band, xp[j] = lower + j*resolution
 // (numpy/core/src/multiarray/compiled_base.c, arr_interp: interval by search, then
@@ -241,28 +287,36 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
                                                                double * __restrict__ out,
                                                                long long level_stride, int accumulate)
 {
-    const long long first = (long long)blockIdx.x*(256*kInterpPoints) + threadIdx.x;
+    // Points of a thread: pairs of neighbours (one 16-byte access where alignment allows),
+    // pairs 512 apart.  point_index(p) for p = 0..PT-1.
+    static_assert(kInterpPoints == 1 || kInterpPoints % 2 == 0, "points come in pairs");
+    const long long block_first = (long long)blockIdx.x*(256*kInterpPoints);
+    auto point_index = [&](int p) -> long long {
+        return kInterpPoints == 1 ? block_first + threadIdx.x
+                                  : block_first + (p >> 1)*512 + 2*threadIdx.x + (p & 1);
+    };
     const int level0 = blockIdx.y*kInterpLevels;
     const int count = min(kInterpLevels, n_levels - level0);
     double x[kInterpPoints];
-#pragma unroll
-    for (int p = 0; p < kInterpPoints; ++p)
-    {
-        const long long i = first + p*256;
-        x[p] = i < n ? wavenumber[i] : __builtin_nan("");
-    }
+    load_points<kInterpPoints>(wavenumber, n, point_index, x, __builtin_nan(""));
     double total[kInterpPoints][kInterpLevels], before[kInterpPoints][kInterpLevels];
 #pragma unroll
-    for (int p = 0; p < kInterpPoints; ++p)
+    for (int l = 0; l < kInterpLevels; ++l)
     {
-        const long long i = first + p*256;
+        double row[kInterpPoints];
 #pragma unroll
-        for (int l = 0; l < kInterpLevels; ++l)
+        for (int p = 0; p < kInterpPoints; ++p) row[p] = 0.;
+        // What is already there, fetched beside the wavenumbers rather than at the end.
+        if (accumulate && l < count)
+        {
+            load_points<kInterpPoints>(out + (long long)(level0 + l)*level_stride, n,
+                                       point_index, row, 0.);
+        }
+#pragma unroll
+        for (int p = 0; p < kInterpPoints; ++p)
         {
             total[p][l] = 0.;
-            // What is already there, fetched beside the wavenumbers rather than at the end.
-            before[p][l] = (accumulate && i < n && l < count)
-                               ? out[(long long)(level0 + l)*level_stride + i] : 0.;
+            before[p][l] = row[p];
         }
     }
     for (int k = 0; k < set.n_bands; ++k)
@@ -327,17 +381,17 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
         }
     }
 #pragma unroll
-    for (int p = 0; p < kInterpPoints; ++p)
+    for (int l = 0; l < kInterpLevels; ++l)
     {
-        const long long i = first + p*256;
-        if (i >= n) continue;
+        if (l >= count) continue;
+        double row[kInterpPoints];
 #pragma unroll
-        for (int l = 0; l < kInterpLevels; ++l)
+        for (int p = 0; p < kInterpPoints; ++p)
         {
-            if (l >= count) continue;
-            double * target = out + (long long)(level0 + l)*level_stride + i;
-            *target = accumulate ? total[p][l] + before[p][l] : total[p][l];
+            row[p] = accumulate ? total[p][l] + before[p][l] : total[p][l];
         }
+        store_points<kInterpPoints>(out + (long long)(level0 + l)*level_stride, n, point_index,
+                                    row);
     }
 }
 

@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "continuum.h"      // load_points / store_points
+
 namespace lbl {
 
 constexpr int kMaxXsecBands = 16;
@@ -131,8 +133,13 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
                                                           long long level_stride, int accumulate)
 {
     __shared__ int window[kMaxXsecBands][2];
+    // Points of a thread as in continuum_interp_kernel: neighbouring pairs, pairs 512 apart.
+    static_assert(PT == 1 || PT % 2 == 0, "points come in pairs");
     const long long block_first = (long long)blockIdx.x*(256*PT);
-    const long long first = block_first + threadIdx.x;
+    auto point_index = [&](int p) -> long long {
+        return PT == 1 ? block_first + threadIdx.x
+                       : block_first + (p >> 1)*512 + 2*threadIdx.x + (p & 1);
+    };
     const int level0 = blockIdx.y*LV;
     const int count = min(LV, n_levels - level0);
     // Search window of every band for this workgroup's points: exact when the grid ascends.
@@ -152,18 +159,27 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
         window[threadIdx.x][1] = hi;
     }
     double x[PT], total[PT][LV], before[PT][LV];
+    load_points<PT>(wavenumber, n, point_index, x, __builtin_nan(""));
 #pragma unroll
     for (int p = 0; p < PT; ++p)
     {
-        const long long i = first + p*256;
-        // Hz, as the reference forms it (cross_section.py:32).
-        x[p] = i < n ? wavenumber[i]*kSpeedOfLight*100 : __builtin_nan("");
+        x[p] = x[p]*kSpeedOfLight*100;      // Hz, as the reference forms it (cross_section.py:32)
+    }
 #pragma unroll
-        for (int l = 0; l < LV; ++l)
+    for (int l = 0; l < LV; ++l)
+    {
+        double row[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) row[p] = 0.;
+        if (accumulate && l < count)
+        {
+            load_points<PT>(out + (long long)(level0 + l)*level_stride, n, point_index, row, 0.);
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
         {
             total[p][l] = 0.;
-            before[p][l] = (accumulate && i < n && l < count)
-                               ? out[(long long)(level0 + l)*level_stride + i] : 0.;
+            before[p][l] = row[p];
         }
     }
     __syncthreads();
@@ -207,17 +223,18 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
         }
     }
 #pragma unroll
-    for (int p = 0; p < PT; ++p)
+    for (int l = 0; l < LV; ++l)
     {
-        const long long i = first + p*256;
-        if (i >= n) continue;
+        if (l >= count) continue;
+        const double density = levels[level0 + l].density;
+        double row[PT];
 #pragma unroll
-        for (int l = 0; l < LV; ++l)
+        for (int p = 0; p < PT; ++p)
         {
-            if (l >= count) continue;
-            const double value = levels[level0 + l].density*total[p][l];
-            out[(long long)(level0 + l)*level_stride + i] = accumulate ? value + before[p][l] : value;
+            const double value = density*total[p][l];
+            row[p] = accumulate ? value + before[p][l] : value;
         }
+        store_points<PT>(out + (long long)(level0 + l)*level_stride, n, point_index, row);
     }
 }
 
