@@ -11,11 +11,13 @@
 //  * Rows that follow each other with the SAME window form a run.  Inside a run only the
 //    two end slots matter, and after every subtraction one of them is exactly zero, so the
 //    state collapses to their difference:  delta <- delta + (V_i(first) - V_i(last)).
-//    Hence for a run with sums VS = sum V_i(first), D = sum (V_i(first) - V_i(last)),
-//    entered with end-slot values (a_s, a_e):
-//        delta_n = (a_s - a_e) + D,   a_s' = max(delta_n, 0),   a_e' = max(-delta_n, 0),
-//        sum of the run's pedestals  P = a_s + VS - a_s',
-//    and every interior slot c receives  sum_i V_i(c) - P.
+//    Hence for a run with sums VS = sum V_i(first), VE = sum V_i(last), entered with
+//    end-slot values (a_s, a_e):  k_s = a_s + VS,  k_e = a_e + VE,
+//        a_s' = max(k_s - k_e, 0),   a_e' = max(k_e - k_s, 0),
+//        sum of the run's pedestals  P = k_s - a_s' = k_e - a_e' = min(k_s, k_e),
+//    taken from the smaller side (the identity that subtracts nothing), so that a line
+//    peak sitting on the other end slot does not cost the small side its accuracy;
+//    every interior slot c receives  sum_i V_i(c) - P.
 //  * The spectrum is then  sum_j V_j(x) - sum_j p_j [x in window_j]; the second sum is
 //    piecewise constant between integer wavenumbers, so the accumulate kernel subtracts one
 //    table value per grid point in its epilogue.
@@ -46,7 +48,7 @@ struct RunMeta
     int first, last;    // the run's window (grid indices, inclusive)
     int n_slots;        // integer slots first/npv .. last/npv (+1 if last is not an integer point)
     double vs;          // sum over the run of V_i(first)
-    double d;           // sum over the run of V_i(first) - V_i(last)
+    double ve;          // sum over the run of V_i(last)
     int bin;            // floor(centre) - (v0 - cut_off - 1): identifies the unclipped window
     int first_slot;     // first/n_per_v
     int last_slot;      // slot of `last`: last/n_per_v, or n_cells when last is the point n-1
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
         const bool extra = (last_int*g.n_per_v != head.last);
         const int n_slots = last_int - first_slot + 1 + (extra ? 1 : 0);
         double * sums = slot_sums + ((long long)level*max_runs + run)*slot_stride;
-        double vs = 0., dd = 0.;
+        double vs = 0., ve = 0.;
         for (int q0 = 0; q0 < n_slots; q0 += 64)
         {
             const int q = q0 + lane;
@@ -280,11 +282,10 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                 {
                     const double at_first = __shfl(value, 0, 64);
                     vs += at_first;
-                    dd += at_first;
                 }
                 if (holds_last)
                 {
-                    dd -= __shfl(value, n_slots - 1 - q0, 64);
+                    ve += __shfl(value, n_slots - 1 - q0, 64);
                 }
             }
             if (active) sums[q] = total;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
             meta.last = head.last;
             meta.n_slots = n_slots;
             meta.vs = vs;
-            meta.d = dd;
+            meta.ve = ve;
             meta.bin = (int)floor(head.centre) - (g.v0 - g.cut_off - 1);
             meta.first_slot = first_slot;
             meta.last_slot = extra ? n_cells : last_int;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void run_links_kernel(const int * __restrict__
     }
     RunLink link;
     link.ks = gs + m.vs;
-    link.ke = ge + (m.vs - m.d);
+    link.ke = ge + m.ve;
     link.mask_s = mask_s;
     link.mask_e = mask_e;
     link.bin = m.bin;
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
                 c = k_s;
             }
         }
+        const double a_own = a, c_own = c;
         for (int offset = 1; offset < kScanBlock; offset <<= 1)
         {
             const double a_left = shuffle_up(a, offset);
@@ -556,7 +558,8 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
         const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
         double before = shuffle_up(total, 1);
         if (lane == 0) before = 0.;
-        const double pedestal = total - before;
+        // P_r = L_r - L_{r-1}; on the branch L_r = L_{r-1} + a it is a itself, exactly.
+        const double pedestal = (before + a_own <= c_own) ? a_own : c_own - before;
         if (active)
         {
             history[r & 127] = pedestal;
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
             const int first_slot = __builtin_amdgcn_readlane(mine.first_slot, r);
             const int last_slot = __builtin_amdgcn_readlane(mine.last_slot, r);
             const double vs = read_lane(mine.vs, r);
-            const double dd = read_lane(mine.d, r);
+            const double ve = read_lane(mine.ve, r);
             const bool bin_ok = bin >= 0 && bin < n_bins;
             if (WINDOW)
             {
@@ -683,10 +686,14 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
                 const double add = interior ? staged[r*slot_stride + (lane - f)] : 0.;
                 const double a_s = read_lane(window, f);
                 const double a_e = read_lane(window, e);
-                const double delta_n = (a_s - a_e) + dd;
+                // The run leaves (k_s, k_e) - min(k_s, k_e) on its end slots and has
+                // subtracted min(k_s, k_e) in all (see the header): taken from the smaller side
+                // directly, so that a line peak on the other end slot costs no accuracy.
+                const double k_s = a_s + vs, k_e = a_e + ve;
+                const double delta_n = k_s - k_e;
                 const double s_new = delta_n > 0. ? delta_n : 0.;
                 const double e_new = delta_n < 0. ? -delta_n : 0.;
-                const double pedestal = n_slots == 1 ? a_s + vs : (a_s + vs) - s_new;
+                const double pedestal = (n_slots == 1 || !(delta_n > 0.)) ? k_s : k_e;
                 double value = window + (add - pedestal);
                 if (!interior) value = window;
                 if (lane == e) value = e_new;
@@ -703,10 +710,11 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
             const double bin_old = bins[bin_ok ? bin : 0];
             const double mid = interior ? a[first_slot + lane] : 0.;
             const double add = interior ? staged[r*slot_stride + lane] : 0.;
-            const double delta_n = (a_s - a_e) + dd;
+            const double k_s = a_s + vs, k_e = a_e + ve;
+            const double delta_n = k_s - k_e;
             const double s_new = delta_n > 0. ? delta_n : 0.;
             const double e_new = delta_n < 0. ? -delta_n : 0.;
-            const double pedestal = n_slots == 1 ? a_s + vs : (a_s + vs) - s_new;
+            const double pedestal = (n_slots == 1 || !(delta_n > 0.)) ? k_s : k_e;
             // One wavefront owns this memory: its LDS accesses execute in program order, so
             // only the compiler has to be kept from reordering them.
             __builtin_amdgcn_wave_barrier();

@@ -21,9 +21,8 @@ def engine():
     e.close()
 
 
-# 64 cases in the regular run; PYLBL_FUZZ_CASES=2000 for a soak.
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PYLBL_FUZZ_CASES", "64"))))
-def test_random_case(engine, oracle, seed):
+def make_case(seed):
+    """The seeded random case as a dictionary (also used by tests/diag_fuzz.py)."""
     rng = np.random.default_rng(1000 + seed)
     v0 = int(rng.integers(1, 3000))
     span = int(rng.integers(1, 60))
@@ -48,24 +47,34 @@ def test_random_case(engine, oracle, seed):
         order = rng.permutation(n_lines)            # rows out of order (range rule matters)
     table = table.subset(order)
     levels = int(rng.integers(1, 4))
-    t = rng.uniform(150., 800., levels)
-    p = 10.**rng.uniform(-2., 6.7, levels)
-    x = 10.**rng.uniform(-7., -0.5, levels)
-    ped = bool(rng.integers(0, 2))
-    policy = "skip" if rng.random() < 0.3 else "reference"
-    engine.set_option("farfield", int(rng.integers(0, 2)))
-    engine.set_option("prep", int(rng.random() < 0.2))
-    engine.set_option("points_per_lane", int(rng.choice([0, 0, 1, 2, 4, 8])))
-    engine.set_option("aligned_tiles", int(rng.random() < 0.3))
-    engine.set_option("scan_chain", int(rng.random() < 0.8))
+    case = dict(v0=v0, vn=vn, npv=npv, cut=cut, n_lines=n_lines, table=table, levels=levels,
+                t=rng.uniform(150., 800., levels), p=10.**rng.uniform(-2., 6.7, levels),
+                x=10.**rng.uniform(-7., -0.5, levels), ped=bool(rng.integers(0, 2)),
+                policy="skip" if rng.random() < 0.3 else "reference")
+    case["options"] = dict(farfield=int(rng.integers(0, 2)), prep=int(rng.random() < 0.2),
+                           points_per_lane=int(rng.choice([0, 0, 1, 2, 4, 8])),
+                           aligned_tiles=int(rng.random() < 0.3),
+                           scan_chain=int(rng.random() < 0.8))
+    source = table
+    if case["policy"] == "skip":
+        source = table.subset((table.nu >= v0 - (cut + 1)) & (table.nu <= vn + cut + 1))
+    case["source"] = source         # what the reference sees under the same policy
+    return case
+
+
+# 64 cases in the regular run; PYLBL_FUZZ_CASES=2000 for a soak.
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PYLBL_FUZZ_CASES", "64"))))
+def test_random_case(engine, oracle, seed):
+    c = make_case(seed)
+    v0, vn, npv, cut, ped, policy = c["v0"], c["vn"], c["npv"], c["cut"], c["ped"], c["policy"]
+    t, p, x, table, source = c["t"], c["p"], c["x"], c["table"], c["source"]
+    for name, value in c["options"].items():
+        engine.set_option(name, value)
     molecule = engine.load(table)
     try:
         got = engine.compute(molecule, t, p, x, v0, vn, npv, cut_off=cut, remove_pedestal=ped,
                              range_policy=policy)
-        source = table
-        if policy == "skip":
-            source = table.subset((table.nu >= v0 - (cut + 1)) & (table.nu <= vn + cut + 1))
-        for level in range(levels):
+        for level in range(c["levels"]):
             k_ref, _ = oracle.absorption_port(source, t[level], p[level], x[level], v0, vn, npv,
                                               cut_off=cut, remove_pedestal=ped)
             k_plain, _ = oracle.absorption_port(source, t[level], p[level], x[level], v0, vn, npv,
@@ -73,7 +82,8 @@ def test_random_case(engine, oracle, seed):
             case = golden_io.Case("fuzz", seed, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
             assert_spectrum(got[level], k_ref, case,
                             f"seed {seed} level {level}: v0={v0} vn={vn} npv={npv} cut={cut} "
-                            f"lines={n_lines} ped={ped} policy={policy} p={p[level]:.3g}", k_plain)
+                            f"lines={c['n_lines']} ped={ped} policy={policy} p={p[level]:.3g}",
+                            k_plain)
     finally:
         engine.free(molecule)
         for name, value in (("farfield", 0), ("prep", 0), ("points_per_lane", 0),

@@ -36,6 +36,13 @@ def assert_spectrum(k, k_ref, case, label, k_plain=None):
         tol = golden_io.pedestal_tolerance(k_ref, case.n_per_v, case.cut_off, REL)
         if k_plain is not None:
             tol = np.maximum(tol, REL*np.abs(k_plain))
+            # Where a pedestal as large as a line peak is subtracted and a later, negative one
+            # adds it back (both window ends on line centres), the reference absorbs and loses
+            # the small values in between and returns exact zeros; any other order of the same
+            # additions leaves rounding residue of the size eps x that peak.  1e-13 of the largest
+            # un-pedestalled value within a window is far below anything that carries meaning.
+            tol = np.maximum(tol, golden_io.pedestal_tolerance(k_plain, case.n_per_v,
+                                                               case.cut_off, 1.e-13))
             growth = np.max(np.abs(k_ref))/max(np.max(np.abs(k_plain)), 1e-300)
             tol = tol*max(1., growth)
         tol += 1e-300
