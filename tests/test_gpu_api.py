@@ -165,7 +165,9 @@ def test_asynchronous_pedestal_calls_share_the_gpu(oracle):
     atmos = synthetic.fixture_atmosphere()
     v0, vn, npv = 1, 91, 40
     outs = [DeviceSpectra(e, 4, (vn - v0)*npv) for _ in tables]
-    for _ in range(2):      # second round reuses every lane's workspace
+    import os
+    # The second round reuses every lane's workspace; PYLBL_SOAK_ROUNDS=500 for a soak.
+    for _ in range(int(os.environ.get("PYLBL_SOAK_ROUNDS", "2"))):
         for h, t, out in zip(handles, tables, outs):
             e.compute(h, atmos.t, atmos.p, atmos.vmr[t.formula], v0, vn, npv,
                       remove_pedestal=True, out=out, asynchronous=True)

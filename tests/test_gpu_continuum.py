@@ -208,3 +208,34 @@ def test_spectroscopy_continuum_slot(continuum_oracle, tmp_path):
     assert not np.asarray(plain["H2O_absorption"])[:, 1:].any()
     with pytest.raises(KeyError):
         Spectroscopy(atmos, grid, None, continua_backend="not-a-model")
+
+
+def test_compute_absorption_is_reproducible_call_to_call(tmp_path):
+    """Results travel on a copy stream into recycled page-locked arrays beside the next gas's
+    kernels: every call must return the same bits (PYLBL_SOAK_ROUNDS=200 for a soak)."""
+    import gc
+    import os
+    from pylbl_amd import Spectroscopy
+    from pylbl_amd.database import Database, write_database
+    atmos = synthetic.fixture_atmosphere()
+    tables = [synthetic.line_table(formula, 1., 230., num_lines=2000 if formula in ("H2O", "CO2", "O3")
+                                   else 5, seed=91 + i, tips_range=(150, 400))
+              for i, formula in enumerate(atmos.vmr)]
+    path = tmp_path / "lines.db"
+    write_database(path, tables, with_tips={"H2O", "CO2", "O3"})
+    grid = np.arange(1., 200., 0.01)
+    spec = Spectroscopy(atmos, grid, Database(str(path)))
+    first = {}
+    for round_ in range(int(os.environ.get("PYLBL_SOAK_ROUNDS", "3"))):
+        for output_format in ("all", "gas", "total"):
+            out = spec.compute_absorption(output_format=output_format)
+            for key, value in out.items():
+                if key in ("wavenumber", "mechanism"):
+                    continue
+                value = np.asarray(value)
+                if round_ == 0:
+                    first[(output_format, key)] = value.copy()
+                else:
+                    assert np.array_equal(value, first[(output_format, key)]), (round_, key)
+            del out
+            gc.collect()
