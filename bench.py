@@ -76,7 +76,7 @@ def parse():
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
-    parser.add_argument("--cpu-sample-cm", type=float, default=600.,
+    parser.add_argument("--cpu-sample-cm", type=float, default=3000.,
                         help="width [cm-1] of the grid sample the CPU baseline is timed on")
     return parser.parse_args()
 
