@@ -181,7 +181,11 @@ class PinnedPool(object):
             self.idle_bytes -= capacity
         else:
             capacity, handle = nbytes, c_void_p()
-            engine._check(engine.lib.lbl_host_alloc(engine.handle, capacity, byref(handle)))
+            if engine.lib.lbl_host_alloc(engine.handle, capacity, byref(handle)) != LBL_OK:
+                # No more page-locked memory to be had (results held by the caller count):
+                # ordinary memory still works, copies into it are only slower.
+                self.clear()
+                return np.empty(shape, dtype=np.float64)
             pointer = handle.value
         from ctypes import c_char
         buffer = (c_char*capacity).from_address(pointer)
