@@ -1,0 +1,249 @@
+"""Every BASELINE.json workload at its full size, every grid point, against the CPU oracle.
+
+The oracle (oracle/lbl_oracle.c, pinned bit-for-bit to the reference's compiled C by
+tests/test_oracle_golden.py) does ~1.2e9 evaluations per second and core, so whole 5 M- and
+10 M-point spectra are affordable when the (molecule, level, mode) calls are farmed out over
+the host cores (tests/oracle_farm.py).  All jobs are queued when the first test of this file
+starts and run beside the GPU work of the others.
+
+What is compared (labels contain "baseline"; none of them may need the growth-scaled
+pedestal tolerance, see test_gpu_zz_tolerance_report.py):
+
+  configs[0]  CO2, 500-800 @ 0.1: the bench's in-range table AND a 1-5000 table whose first
+              row lies below 474 cm-1, so the reference's range `break` (absorption.c:80-83)
+              discards everything; both range policies; pedestal off/on.
+  configs[1]  H2O + CO2, 1-5000 @ 0.01: all 500 k points, pedestal off/on.
+  target      H2O + CO2, 1-5000 @ 0.001 (what bench.py times): all 5 M points, pedestal
+              off AND on (the default through compute_absorption, spectroscopy.py:163-164).
+  configs[2]  the other six README molecules at 5 M points: all points without pedestal,
+              O3 / CO / O2 / N2 also with.
+  configs[3]  shape: 8 standard-atmosphere levels, H2O + CO2 + O3, 1-3000 @ 0.001, one batched
+              call; the surface and the 10 Pa level compared at all 3 M points with pedestal on
+              and off, the levels between through windows.
+  configs[4]  shape: 1-5000 @ 0.0005 (n_per_v = 2000, 10 M points), 4 levels of the 256-level
+              atmosphere; CO / O2 / N2 at all points with pedestal on and off, H2O / CO2 through
+              windows, all levels.
+  banded      a banded CO2 table (split tiles, long pedestal chain) at 5 M points, pedestal on.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from pylbl_amd import synthetic
+from tests import golden_io
+from tests.oracle_farm import OracleFarm, table_from_recipe
+from tests.test_gpu_parity import assert_spectrum
+
+pytestmark = pytest.mark.gpu
+
+SURFACE = synthetic.surface_level()
+OTHERS = ("O3", "N2O", "CO", "CH4", "O2", "N2")
+PEDESTAL_TOO = ("O3", "CO", "O2", "N2")
+STANDARD8 = synthetic.standard_atmosphere(8)
+STANDARD256 = synthetic.standard_atmosphere(256)
+LEVELS256 = (0, 85, 170, 255)
+SMALL = ("CO", "O2", "N2")
+BANDED = ("banded", "CO2", 1., 5000., 300_000, 8, 41)
+
+
+def uniform(formula, v_lo=1., v_hi=5000.):
+    return ("uniform", formula, v_lo, v_hi)
+
+
+def level_of(atmos, formula, level):
+    return float(atmos.t[level]), float(atmos.p[level]), float(atmos.vmr[formula][level])
+
+
+@pytest.fixture(scope="module")
+def farm():
+    f = OracleFarm()
+    # configs[0]
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    for ped in (False, True):
+        f.submit(("c0", "inrange", ped), uniform("CO2", 500., 800.), t, p, x, 500, 801, 10, ped)
+        f.submit(("c0", "wide", ped), uniform("CO2"), t, p, x, 500, 801, 10, ped)
+    # configs[1] and the target
+    for formula in ("H2O", "CO2"):
+        t, p, x = level_of(SURFACE, formula, 0)
+        for ped in (False, True):
+            f.submit(("c1", formula, ped), uniform(formula), t, p, x, 1, 5001, 100, ped)
+            f.submit(("target", formula, ped), uniform(formula), t, p, x, 1, 5001, 1000, ped)
+    # configs[2]: the other six molecules
+    for formula in OTHERS:
+        t, p, x = level_of(SURFACE, formula, 0)
+        f.submit(("c2", formula, False), uniform(formula), t, p, x, 1, 5001, 1000, False)
+        if formula in PEDESTAL_TOO:
+            f.submit(("c2", formula, True), uniform(formula), t, p, x, 1, 5001, 1000, True)
+    # configs[3] shape: first and last of 8 standard-atmosphere levels
+    for formula in ("H2O", "CO2", "O3"):
+        for level in (0, 7):
+            t, p, x = level_of(STANDARD8, formula, level)
+            for ped in (False, True):
+                f.submit(("c3", formula, level, ped), uniform(formula, 1., 3000.), t, p, x,
+                         1, 3001, 1000, ped)
+    # configs[4] shape: 10 M points
+    for formula in SMALL:
+        for level in (LEVELS256[0], LEVELS256[-1]):
+            t, p, x = level_of(STANDARD256, formula, level)
+            for ped in (False, True):
+                f.submit(("c4", formula, level, ped), uniform(formula), t, p, x, 1, 5001, 2000,
+                         ped)
+    # banded table, pedestal on (+ the plain spectrum its tolerance refers to)
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    for ped in (False, True):
+        f.submit(("banded", ped), BANDED, t, p, x, 1, 5001, 1000, ped)
+    f.start()
+    yield f
+    f.close()
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pylbl_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def case_for(v0, vn, npv, ped, index=0):
+    return golden_io.Case("baseline", index, 0, 0, 0, v0, vn, npv, 25, ped, None, 0)
+
+
+def check_full(farm, key_plain, key, k, v0, vn, npv, ped, label, evals=None):
+    k_ref, evals_ref = farm.result(key)
+    if evals is not None:
+        assert evals == evals_ref, f"{label}: eval count {evals} != oracle {evals_ref}"
+    k_plain = farm.result(key_plain)[0] if ped else None
+    assert_spectrum(k, k_ref, case_for(v0, vn, npv, ped), f"baseline {label}", k_plain)
+
+
+def check_windows(oracle, table, k, t, p, x, v0, vn, npv, starts, label, width=2):
+    """Pedestal-free windows: a point only sees lines within cut_off + 1 cm-1, so the oracle on
+    a narrow sub-grid reproduces the matching slice of the full spectrum."""
+    for lo in starts:
+        hi = lo + width
+        g0, g1 = max(lo - 2, v0), min(hi + 2, vn)
+        near = table.subset((table.nu >= g0 - 26.) & (table.nu <= g1 + 26.))
+        k_ref, _ = oracle.absorption_port(near, t, p, x, g0, g1, npv)
+        k_ref = k_ref[(lo - g0)*npv:(hi - g0)*npv]
+        piece = k[(lo - v0)*npv:(hi - v0)*npv]
+        np.testing.assert_allclose(piece, k_ref, rtol=1e-6, err_msg=f"baseline {label} @{lo}")
+
+
+def test_config0_co2_500_800(farm, engine):
+    """configs[0] through the reference-shaped Gas object, incl. the range `break` quirk."""
+    from pylbl_amd import Gas
+    grid = np.arange(500., 800., 0.1)
+    assert synthetic.grid_arguments(grid) == (500, 801, 10)
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    inrange = table_from_recipe(uniform("CO2", 500., 800.))
+    wide = table_from_recipe(uniform("CO2"))
+    assert wide.nu[0] < 474.            # absorption.c:80-83 fires on the very first row
+    for ped in (False, True):
+        gas = Gas(inrange, "CO2", engine=engine)
+        k = gas.absorption_coefficient(t, p, x, grid, remove_pedestal=ped)
+        assert k.size == 3010 and k[:grid.size].any()
+        check_full(farm, ("c0", "inrange", False), ("c0", "inrange", ped), k, 500, 801, 10, ped,
+                   f"config0 in-range table ped={ped}")
+        gas = Gas(wide, "CO2", engine=engine)
+        with pytest.warns(RuntimeWarning, match="first transition"):
+            k = gas.absorption_coefficient(t, p, x, grid, remove_pedestal=ped)
+        k_ref, _ = farm.result(("c0", "wide", ped))
+        assert not k_ref.any() and not k.any()     # the reference computes nothing here
+        # "skip" policy = the reference on the rows inside its own range.
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            k = gas.absorption_coefficient(t, p, x, grid, remove_pedestal=ped,
+                                           range_policy="skip")
+        inside = wide.subset((wide.nu >= 500 - 26.) & (wide.nu <= 801 + 26.))
+        from oracle import oracle
+        k_ref, _ = oracle.absorption_port(inside, t, p, x, 500, 801, 10, remove_pedestal=ped)
+        k_plain, _ = oracle.absorption_port(inside, t, p, x, 500, 801, 10)
+        assert_spectrum(k, k_ref, case_for(500, 801, 10, ped), f"baseline config0 skip ped={ped}",
+                        k_plain)
+
+
+@pytest.mark.parametrize("name,npv", [("c1", 100), ("target", 1000)])
+def test_h2o_co2_whole_grid(farm, engine, name, npv):
+    """configs[1] (0.01 cm-1) and the target (0.001 cm-1): every point, both modes."""
+    for formula in ("H2O", "CO2"):
+        t, p, x = level_of(SURFACE, formula, 0)
+        handle = engine.load(table_from_recipe(uniform(formula)))
+        for ped in (False, True):
+            k, evals = engine.compute(handle, t, p, x, 1, 5001, npv, remove_pedestal=ped,
+                                      want_evals=True)
+            check_full(farm, (name, formula, False), (name, formula, ped), k[0], 1, 5001, npv,
+                       ped, f"{name} {formula} ped={ped}", evals)
+        engine.free(handle)
+
+
+def test_config2_other_molecules(farm, engine):
+    for formula in OTHERS:
+        t, p, x = level_of(SURFACE, formula, 0)
+        handle = engine.load(table_from_recipe(uniform(formula)))
+        for ped in (False, True):
+            if ped and formula not in PEDESTAL_TOO:
+                continue
+            k, evals = engine.compute(handle, t, p, x, 1, 5001, 1000, remove_pedestal=ped,
+                                      want_evals=True)
+            check_full(farm, ("c2", formula, False), ("c2", formula, ped), k[0], 1, 5001, 1000,
+                       ped, f"config2 {formula} ped={ped}", evals)
+        engine.free(handle)
+
+
+def test_config3_shape_standard_atmosphere(farm, engine, oracle):
+    """8 levels from 1013 hPa to 0.1 hPa in ONE batched call per molecule."""
+    for formula in ("H2O", "CO2", "O3"):
+        table = table_from_recipe(uniform(formula, 1., 3000.))
+        handle = engine.load(table)
+        spectra = {}
+        for ped in (False, True):
+            spectra[ped] = engine.compute(handle, STANDARD8.t, STANDARD8.p,
+                                          STANDARD8.vmr[formula], 1, 3001, 1000,
+                                          remove_pedestal=ped)
+            for level in (0, 7):
+                check_full(farm, ("c3", formula, level, False), ("c3", formula, level, ped),
+                           spectra[ped][level], 1, 3001, 1000, ped,
+                           f"config3 {formula} level {level} ped={ped}")
+        for level in range(1, 7):
+            t, p, x = level_of(STANDARD8, formula, level)
+            check_windows(oracle, table, spectra[False][level], t, p, x, 1, 3001, 1000,
+                          (1, 700 + 37*level, 2998), f"config3 {formula} level {level}", width=1)
+        engine.free(handle)
+
+
+def test_config4_shape_ten_million_points(farm, engine, oracle):
+    """n_per_v = 2000: windows of 102 001 points, tiles of 512."""
+    t4, p4 = STANDARD256.t[list(LEVELS256)], STANDARD256.p[list(LEVELS256)]
+    for formula in SMALL + ("H2O", "CO2"):
+        table = table_from_recipe(uniform(formula))
+        x4 = STANDARD256.vmr[formula][list(LEVELS256)]
+        handle = engine.load(table)
+        modes = (False, True) if formula in SMALL else (False,)
+        for ped in modes:
+            k = engine.compute(handle, t4, p4, x4, 1, 5001, 2000, remove_pedestal=ped)
+            assert k.shape == (4, 10_000_000)
+            if formula in SMALL:
+                for row, level in ((0, LEVELS256[0]), (3, LEVELS256[-1])):
+                    check_full(farm, ("c4", formula, level, False), ("c4", formula, level, ped),
+                               k[row], 1, 5001, 2000, ped,
+                               f"config4 {formula} level {level} ped={ped}")
+            if not ped:
+                for row in range(4):
+                    check_windows(oracle, table, k[row], t4[row], p4[row], x4[row], 1, 5001,
+                                  2000, (1, 1200 + 301*row, 4999),
+                                  f"config4 {formula} level {LEVELS256[row]}", width=1)
+        engine.free(handle)
+
+
+def test_banded_table_whole_grid_pedestal(farm, engine):
+    """Dense bands: tiles split into many work items, thousands of windows per pedestal run."""
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    handle = engine.load(table_from_recipe(BANDED))
+    for ped in (False, True):
+        k, evals = engine.compute(handle, t, p, x, 1, 5001, 1000, remove_pedestal=ped,
+                                  want_evals=True)
+        check_full(farm, ("banded", False), ("banded", ped), k[0], 1, 5001, 1000, ped,
+                   f"banded CO2 ped={ped}", evals)
+    engine.free(handle)

@@ -18,6 +18,12 @@ def engine():
     e.close()
 
 
+# Every pedestal comparison that needed more than the plain SURVEY 8(c) metric leaves a record
+# here; tests/test_gpu_zz_tolerance_report.py prints them and bounds their number.
+GROWTH_CAP = 100.
+TOLERANCE_LOG = {"compared": 0, "scaled": [], "baseline": []}
+
+
 def assert_spectrum(k, k_ref, case, label, k_plain=None):
     """k_plain (optional): the reference spectrum WITHOUT pedestal removal.  With the pedestal
     removed a value is (sum of profiles) - (sum of pedestals); where the two cancel (the
@@ -30,10 +36,12 @@ def assert_spectrum(k, k_ref, case, label, k_plain=None):
     the un-pedestalled spectrum, and the last-bit differences between two correct fp64
     evaluations of the profiles grow by the same factor (found by a 2000-case soak: 1.03e-6 of
     the local maximum after 2843 such lines, rising smoothly with the number of rows).  The
-    tolerance is scaled by that growth, max|k_ref| / max|k_plain|, where it exceeds one."""
+    tolerance is scaled by that growth, max|k_ref| / max|k_plain|, where it exceeds one -- but
+    never by more than GROWTH_CAP, and every case that needed the scaling is logged."""
     assert k.shape == k_ref.shape
     if case.remove_pedestal:
         tol = golden_io.pedestal_tolerance(k_ref, case.n_per_v, case.cut_off, REL)
+        TOLERANCE_LOG["compared"] += 1
         if k_plain is not None:
             tol = np.maximum(tol, REL*np.abs(k_plain))
             # Where a pedestal as large as a line peak is subtracted and a later, negative one
@@ -44,15 +52,27 @@ def assert_spectrum(k, k_ref, case, label, k_plain=None):
             tol = np.maximum(tol, golden_io.pedestal_tolerance(k_plain, case.n_per_v,
                                                                case.cut_off, 1.e-13))
             growth = np.max(np.abs(k_ref))/max(np.max(np.abs(k_plain)), 1e-300)
-            tol = tol*max(1., growth)
+            if growth > 1.:
+                unscaled = float(np.max(np.abs(k - k_ref)/(tol + 1e-300)))
+                if unscaled > 1.:
+                    # Only cases that actually need the scaling are logged and scaled.
+                    factor = min(growth, GROWTH_CAP)
+                    TOLERANCE_LOG["scaled"].append(
+                        {"label": label, "growth": float(growth), "factor": float(factor),
+                         "worst_unscaled": unscaled})
+                    tol = tol*factor
         tol += 1e-300
         worst = np.max(np.abs(k - k_ref)/tol)
+        if label.startswith("baseline"):
+            TOLERANCE_LOG["baseline"].append((label, k.size, float(worst), "x pedestal tolerance"))
         assert worst <= 1., f"{label}: {worst:.3g} x the pedestal tolerance"
     else:
         nz = k_ref != 0
         assert np.array_equal(k[~nz], k_ref[~nz]), f"{label}: nonzero where reference is zero"
         if nz.any():
             worst = np.max(np.abs(k[nz] - k_ref[nz])/np.abs(k_ref[nz]))
+            if label.startswith("baseline"):
+                TOLERANCE_LOG["baseline"].append((label, k.size, float(worst), "max relative"))
             assert worst <= REL, f"{label}: max rel err {worst:.3g}"
 
 
