@@ -89,8 +89,15 @@ int lbl_compute(lbl_engine *engine, int32_t molecule, int32_t n_levels,
                 int32_t remove_pedestal, int32_t range_policy, int32_t flags,
                 double *k, int64_t level_stride, int64_t *evals);
 
-/* Waits for everything enqueued on the engine's stream. */
+/* Waits for everything enqueued on the engine (all of its streams). */
 int lbl_synchronize(lbl_engine *engine);
+
+/* Zeroes n_levels rows of n doubles (row stride level_stride, 0 = dense) of host memory, or of
+ * device memory with LBL_OUT_DEVICE (LBL_ASYNC: queued like a compute call).  What the reference
+ * returns for a molecule without partition-function rows or transitions (absorption.c:41,
+ * :53-59): hosts use it to give a caller-supplied output buffer those semantics. */
+int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
+                  int64_t level_stride, int32_t flags);
 
 /* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1:
  * record HIP events around every kernel), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
@@ -105,7 +112,9 @@ int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
  * interpolation.  Synchronizes the streams. */
 int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t reset);
 
-/* The engine's HIP stream (a hipStream_t), for callers that time with their own events. */
+/* The engine's first HIP stream (a hipStream_t), for callers that time with their own events.
+ * Plain calls run on it back to back; asynchronous calls with remove_pedestal rotate over
+ * several streams, so events on this one do not bracket them (use lbl_synchronize / lbl_timing). */
 void *lbl_stream(lbl_engine *engine);
 
 /* Device memory helpers so that hosts without a HIP binding can keep spectra in HBM. */
@@ -236,12 +245,33 @@ int lbl_xsec_bands(lbl_engine *engine, int32_t xsec, double temperature, double 
                    double *values);
 
 /* Same signature and semantics as the reference's absorption() (absorption.c:19-30):
- * opens the SQLite file, uploads the molecule (cached per path+formula for the life of the
- * process), computes one level on device 0.  Returns 0 on success, 1 on error (message on
- * stderr), 0 with zeros when the molecule has no TIPS rows (absorption.c:53-59). */
+ * opens the SQLite file, uploads the molecule, computes one level.  Returns 0 on success, 1 on
+ * error (message on stderr), 0 with zeros when the molecule has no TIPS rows
+ * (absorption.c:53-59).
+ *   Device: LBL_DEVICE if set, else LOCAL_RANK / OMPI_COMM_WORLD_LOCAL_RANK / SLURM_LOCALID
+ *   modulo the visible devices, else 0 (indices relative to HIP_VISIBLE_DEVICES), fixed at the
+ *   first call of the process.
+ *   Residency: the uploaded line table is kept per (path, formula) and re-read when the file's
+ *   mtime, size or inode changed; at most LBL_COMPAT_CACHE (default 16) molecules stay in HBM,
+ *   least recently used evicted first. */
 int lbl_absorption(double pressure, double temperature, double volume_mixing_ratio,
                    int v0, int vn, int n_per_v, double *k, char *database, char *formula,
                    int cut_off, int remove_pedestal);
+
+/* The reference's own symbol (pyLBL/c_lib/absorption.c:19-30, bound by
+ * pyLBL/c_lib/gas_optics.py:11-12,68-91): an alias of lbl_absorption, exported so that this
+ * library, installed as libabsorption*.so beside gas_optics.py, serves an unmodified pyLBL.
+ * Define LBL_NO_REFERENCE_SYMBOL before including this header when the reference's own
+ * absorption.h is in the same translation unit. */
+#ifndef LBL_NO_REFERENCE_SYMBOL
+int absorption(double pressure, double temperature, double volume_mixing_ratio,
+               int v0, int vn, int n_per_v, double *k, char *database, char *formula,
+               int cut_off, int remove_pedestal);
+#endif
+
+/* State of the compatibility entry: the device it computes on (-1 before its first call) and
+ * the number of molecules it keeps in HBM. */
+int lbl_compat_state(int32_t *device, int32_t *resident);
 
 /* Library version string. */
 const char *lbl_version(void);

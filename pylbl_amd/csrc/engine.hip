@@ -95,6 +95,11 @@ struct Molecule
     std::vector<int> iso_slot;              // sorted
     double mass[kMassSlots];
     unsigned used_slots = 0;                // bit per isotopologue slot that has lines
+    // Rows whose local_iso_id has no mass or no partition-function row.  The reference reads
+    // past its tables for them (spectra.c:41-42); here they are an error -- but only when a
+    // compute call would actually reach them (rows behind the range `break` never are).
+    struct BadRow { int row; double nu; int local_iso_id; };
+    std::vector<BadRow> bad_rows;
     double max_abs_delta = 0.;
     int num_iso = 0, num_t = 0;
     std::vector<double> tips_t, tips_q;
@@ -139,6 +144,8 @@ struct Lane
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
     hipEvent_t runs_found = nullptr;
     hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
+    hipEvent_t finished = nullptr;  // end of the last call that wrote device output on this lane
+    const char * out_begin = nullptr, * out_end = nullptr;     // ... and where it wrote
     bool levels_in_flight = false;
     DeviceBuffer<LineWing> wing;
     DeviceBuffer<LineCore> core;
@@ -165,6 +172,7 @@ struct Lane
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&finished, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
     }
@@ -182,6 +190,7 @@ struct Lane
         if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
         if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
         if (queued != nullptr) (void)hipEventDestroy(queued);
+        if (finished != nullptr) (void)hipEventDestroy(finished);
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
         if (side != nullptr) (void)hipStreamDestroy(side);
@@ -627,6 +636,16 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
     rule.nu_min = rq.v0 - (rq.cut_off + 1);
     rule.nu_max = rq.vn + rq.cut_off + 1;
     rule.row_limit = first_row_out_of_range(*m, rule.nu_min, rule.nu_max);
+    for (const auto & bad : m->bad_rows)
+    {
+        if (line_accepted(rule, bad.nu, bad.row))
+        {
+            return fail(engine, LBL_OUT_OF_RANGE,
+                        "row " + std::to_string(bad.row) + ": local_iso_id " +
+                        std::to_string(bad.local_iso_id) +
+                        " has no mass or no partition-function row.");
+        }
+    }
 
     Tiling tiling;
     const int points = pick_tiling(engine, rq.n_per_v, n_long, tiling);
@@ -651,6 +670,21 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
         }
         hipStream_t stream = lane.main;
+        if (alternate && out_device)
+        {
+            // Calls on different lanes run side by side; two that write the same memory must
+            // not: the later one waits for the earlier one's last kernel.
+            const char * begin = reinterpret_cast<const char *>(rq.k);
+            const char * end = begin + ((long long)(rq.n_levels - 1)*stride + n_long)*8;
+            for (auto & other : engine->lanes)
+            {
+                if (&other != &lane && other.out_begin != nullptr && begin < other.out_end &&
+                    other.out_begin < end)
+                {
+                    HIP_TRY(hipStreamWaitEvent(stream, other.finished, 0));
+                }
+            }
+        }
 
         Molecule::Plan & plan = plan_for(engine, *m, g, tiling, points, stream);
 
@@ -722,14 +756,15 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 {
                     for (long long j = 0; j < n_lines; ++j)
                     {
-                        const bool ok = line_accepted(rule, m->column[0][j], m->order[j]);
+                        const bool ok = m->iso_slot[j] >= 0 &&
+                                        line_accepted(rule, m->column[0][j], m->order[j]);
                         double * d = (rq.derived != nullptr && l == 0)
                                      ? host_derived.data() + j*8 : nullptr;
                         LineWing & w = host_wing[(size_t)(l*n_lines + j)];
                         const int status = prepare_line(
                             lane.pinned_levels[l], g, m->column[0][j], m->column[1][j],
                             m->column[2][j], m->column[3][j], m->column[4][j], m->column[5][j],
-                            m->column[6][j], m->iso_slot[j], ok, w,
+                            m->column[6][j], std::max(m->iso_slot[j], 0), ok, w,
                             host_core[(size_t)(l*n_lines + j)], d);
                         if (status == 1 && w.last >= w.first) total += w.last - w.first + 1;
                     }
@@ -904,6 +939,12 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
         }
 
+        if (out_device && want_k)
+        {
+            HIP_TRY(hipEventRecord(lane.finished, stream));
+            lane.out_begin = reinterpret_cast<const char *>(rq.k);
+            lane.out_end = lane.out_begin + ((long long)(rq.n_levels - 1)*stride + n_long)*8;
+        }
         if (rq.evals != nullptr && !(engine->prep == LBL_PREP_HOST))
         {
             unsigned long long total = 0;
@@ -1075,10 +1116,10 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
             const int slot = iso - 1;
             if (slot < 0 || slot >= kMassSlots || slot >= num_iso || !(m->mass[slot] > 0.))
             {
-                return fail(engine, LBL_OUT_OF_RANGE,
-                            "row " + std::to_string(m->order[j]) + ": local_iso_id " +
-                            std::to_string(local_iso_id[m->order[j]]) +
-                            " has no mass or no partition-function row.");
+                m->bad_rows.push_back(Molecule::BadRow{m->order[j], m->column[0][j],
+                                                       local_iso_id[m->order[j]]});
+                m->iso_slot[j] = -1;        // never evaluated (prepare_kernel / host prep)
+                continue;
             }
             m->iso_slot[j] = slot;
             m->used_slots |= 1u << slot;
@@ -1277,10 +1318,51 @@ int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int6
         return LBL_BAD_ARGUMENT;
     }
     (void)hipSetDevice(engine->device);
-    hipError_t status = hipMemcpyAsync(host, device, (size_t)bytes, hipMemcpyDeviceToHost,
-                                       engine->stream);
+    // The memory may have been written on any lane (asynchronous calls with a pedestal rotate
+    // over them): wait for all of them, not only for lane 0.
+    hipError_t status = hipSuccess;
+    for (auto & lane : engine->lanes)
+    {
+        if (status == hipSuccess) status = hipStreamSynchronize(lane.main);
+    }
+    if (status == hipSuccess)
+    {
+        status = hipMemcpyAsync(host, device, (size_t)bytes, hipMemcpyDeviceToHost,
+                                engine->stream);
+    }
     if (status == hipSuccess) status = hipStreamSynchronize(engine->stream);
     if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
+    return LBL_OK;
+}
+
+int lbl_fill_zero(lbl_engine * engine, double * k, int32_t n_levels, int64_t n,
+                  int64_t level_stride, int32_t flags)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (k == nullptr || n_levels < 0 || n < 0 || (level_stride != 0 && level_stride < n))
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "lbl_fill_zero: bad argument.");
+    }
+    const int64_t stride = level_stride > 0 ? level_stride : n;
+    if (n_levels == 0 || n == 0) return LBL_OK;
+    if (!(flags & LBL_OUT_DEVICE))
+    {
+        for (int32_t l = 0; l < n_levels; ++l) std::memset(k + l*stride, 0, (size_t)n*8);
+        return LBL_OK;
+    }
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        // Ordered like a plain compute call: after everything queued on the other lanes.
+        for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+        HIP_TRY(hipMemset2DAsync(k, (size_t)stride*8, 0, (size_t)n*8, (size_t)n_levels,
+                                 engine->stream));
+        if (!(flags & LBL_ASYNC)) HIP_TRY(hipStreamSynchronize(engine->stream));
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
     return LBL_OK;
 }
 

@@ -59,11 +59,12 @@ __global__ __launch_bounds__(256) void prepare_kernel(const LineTableView t,
         LineWing w;
         LineCore c;
         const double nu = t.nu[j];
-        const bool ok = line_accepted(rule, nu, t.row[j]);
+        const int slot = t.iso_slot[j];     // -1: no mass / partition function (never accepted)
+        const bool ok = slot >= 0 && line_accepted(rule, nu, t.row[j]);
         double * d = derived != nullptr ? derived + ((long long)level*t.n_lines + j)*8 : nullptr;
         const int status = prepare_line(levels[level], g, nu, t.sw[j], t.gamma_air[j],
                                         t.gamma_self[j], t.n_air[j], t.elower[j],
-                                        t.delta_air[j], t.iso_slot[j], ok, w, c, d);
+                                        t.delta_air[j], max(slot, 0), ok, w, c, d);
         wing[(long long)level*t.n_lines + j] = w;
         core[(long long)level*t.n_lines + j] = c;
         if (status == 1 && w.last >= w.first)

@@ -76,21 +76,37 @@ class LineTable:
 
 
 class TotalPartitionFunction(object):
-    """TIPS table with the reference's interpolation (pyLBL/tips.py:26-39)."""
+    """Total internal partition sums Q(T) of one molecule, tabulated per isotopologue on a
+    common temperature axis: the host-side twin of spectral_database.c:97-104 and of the
+    object the reference's Database.gas() hands out (pyLBL/tips.py:9-39).
+
+    Attributes:
+        molecule: Chemical formula.
+        temperature: float64[num_t], ascending [K].
+        data: float64[num_iso, num_t].
+    """
     def __init__(self, molecule, temperature, data):
         self.molecule = molecule
-        self.temperature = temperature
-        self.data = data
+        self.temperature = np.asarray(temperature, dtype=np.float64)
+        self.data = np.asarray(data, dtype=np.float64)
+        if self.data.ndim != 2 or self.data.shape[1] != self.temperature.size:
+            raise ValueError("data must be [num_iso, num_t] on the temperature axis.")
 
     @property
     def isotopologue(self):
-        return [x for x in range(self.data.shape[0])]
+        """Row indices of the table (0-based), one per isotopologue."""
+        return list(range(len(self.data)))
 
     def total_partition_function(self, temperature, isotopologue):
-        i = isotopologue - 1
-        j = np.searchsorted(self.temperature, temperature, side="left") - 1
-        return self.data[i, j] + (self.data[i, j+1] - self.data[i, j]) * \
-            (temperature - self.temperature[j])/(self.temperature[j+1] - self.temperature[j])
+        """Q(temperature) of the 1-based `isotopologue`, linear between the two tabulated
+        temperatures that bracket it (the lower one strictly below `temperature`, as the
+        reference's left-sided search chooses it)."""
+        row = self.data[isotopologue - 1]
+        axis = self.temperature
+        lower = int(np.searchsorted(axis, temperature, side="left")) - 1
+        t0, t1 = axis[lower], axis[lower + 1]
+        weight = (temperature - t0)/(t1 - t0)
+        return row[lower] + (row[lower + 1] - row[lower])*weight
 
 
 GasData = namedtuple("GasData", ["formula", "mass", "transitions", "partition_function"])

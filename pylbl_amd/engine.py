@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = (
     "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
-    "lbl_line_scalars", "lbl_absorption", "lbl_version",
+    "lbl_line_scalars", "lbl_absorption", "absorption", "lbl_compat_state", "lbl_fill_zero",
+    "lbl_version",
     "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
     "lbl_continuum_compute", "lbl_continuum_bands",
     "lbl_xsec_load", "lbl_xsec_free", "lbl_xsec_compute", "lbl_xsec_bands",
@@ -86,6 +87,9 @@ def library():
     lib.lbl_line_scalars.argtypes = [c_void_p, c_int32] + [c_double]*3 + [c_int32]*6 + [c_void_p]
     lib.lbl_absorption.argtypes = [c_double]*3 + [c_int32]*3 + [c_void_p, c_char_p, c_char_p,
                                   c_int32, c_int32]
+    lib.absorption.argtypes = lib.lbl_absorption.argtypes
+    lib.lbl_compat_state.argtypes = [i32p, i32p]
+    lib.lbl_fill_zero.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32]
     lib.lbl_version.restype = c_char_p
     lib.lbl_continuum_load.argtypes = [c_void_p, c_int32, POINTER(BandDescriptor), c_void_p,
                                        c_int64, i32p]
@@ -303,6 +307,17 @@ class Engine(object):
             RANGE_POLICIES[range_policy], flags, pointer, 0,
             byref(evals) if want_evals else None))
         return (out, evals.value) if want_evals else out
+
+    def fill_zero(self, out, asynchronous=False):
+        """Zeroes a [levels, n] output (host array or DeviceSpectra): the spectrum the
+        reference returns for a molecule it has nothing to compute for (absorption.c:41)."""
+        if hasattr(out, "pointer"):
+            self._check(self.lib.lbl_fill_zero(
+                self.handle, out.pointer, int(out.shape[0]), int(out.shape[1]), 0,
+                OUT_DEVICE | (ASYNC if asynchronous else 0)))
+        else:
+            out[...] = 0.
+        return out
 
     def line_scalars(self, molecule, num_lines, temperature, pressure, vmr, v0, vn, n_per_v,
                      cut_off=25, range_policy="reference"):

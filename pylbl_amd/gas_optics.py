@@ -101,8 +101,11 @@ class Gas(object):
                 RuntimeWarning, stacklevel=3)
         levels = np.atleast_1d(np.asarray(temperature, dtype=np.float64)).size
         if self.molecule is None:
+            # No partition-function rows or no transitions: the reference returns the zeroed
+            # spectrum (absorption.c:41, :53-59), so a caller's buffer must read zero as well
+            # (nothing is added to one that is being accumulated into).
             if out is not None:
-                return out
+                return out if accumulate else self.engine.fill_zero(out, asynchronous)
             return np.zeros((levels, (vn - v0)*n_per_v))
         return self.engine.compute(self.molecule, temperature, pressure, volume_mixing_ratio,
                                    v0, vn, n_per_v, cut_off=cut_off,

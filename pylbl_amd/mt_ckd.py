@@ -91,10 +91,19 @@ def _o2_herzberg(tables):
     return O2_HERZBERG, 36000., 10., [shape]
 
 
+def _grid_fingerprint(grid):
+    """Cheap signature of an array's current contents: size, end points and 4096 evenly spaced
+    samples.  (A full checksum of a 5 M-point grid costs as much as the kernels it feeds.)"""
+    step = max(grid.size//4096, 1)
+    return (grid.size, float(grid[0]), float(grid[-1]), hash(grid[::step].tobytes()))
+
+
 def resident_grid(engine, grid):
     """Handle of `grid` in the engine's HBM: uploaded once per array object and shared by all
     continua (the reference is handed the same array for every gas and level,
-    spectroscopy.py:195); copies whose array has been garbage-collected are freed here."""
+    spectroscopy.py:195).  An array whose contents changed since the upload (edited or
+    refilled in place) is uploaded again; copies whose array has been garbage-collected are
+    freed here."""
     cache = engine.__dict__.setdefault("_resident_grids", [])
     found = None
     for entry in list(cache):
@@ -103,14 +112,21 @@ def resident_grid(engine, grid):
             engine.free_grid(entry[1])
             cache.remove(entry)
         elif target is grid:
-            found = entry[1]
+            found = entry
+    fingerprint = _grid_fingerprint(grid)
+    if found is not None and found[2] != fingerprint:
+        engine.synchronize()        # queued kernels may still read the old copy
+        engine.free_grid(found[1])
+        cache.remove(found)
+        found = None
     if found is None:
-        found = engine.load_grid(grid)
+        handle = engine.load_grid(grid)
         try:
-            cache.append((weakref.ref(grid), found))
+            found = (weakref.ref(grid), handle, fingerprint)
         except TypeError:
-            cache.append((lambda: None, found))     # not weak-referenceable: freed next time
-    return found
+            found = (lambda: None, handle, fingerprint)     # not weak-referenceable: freed next time
+        cache.append(found)
+    return found[1]
 
 
 class Band(object):

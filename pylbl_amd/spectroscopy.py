@@ -141,7 +141,10 @@ class Spectroscopy(object):
     def __init__(self, atmosphere, grid, database, mapping=None, lines_backend="mi355x",
                  continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0):
         self.atmosphere = Atmosphere(atmosphere, mapping=mapping)
-        self.grid = np.ascontiguousarray(grid, dtype=np.float64)
+        # A private copy: the grid's device copy is cached per array object, and the lines
+        # path reads (v0, vn, n_per_v) off it on every call -- a caller editing its own array
+        # afterwards must not move one mechanism's grid and leave the others behind.
+        self.grid = np.array(grid, dtype=np.float64, order="C", copy=True)
         self.lines_database = database
         self.lines_backend = lines_backend
         self.lines_engine = molecular_lines[lines_backend]      # KeyError if unknown

@@ -232,10 +232,21 @@ def test_error_paths():
         e.compute(h, 250., 1000., 1e-3, 50, 50, 10)         # empty grid
     with pytest.raises(EngineError):
         e.compute(99, 250., 1000., 1e-3, 1, 50, 10)         # unknown handle
+    # A row whose isotopologue has no mass / partition-function row is an error only when a
+    # call reaches it: the reference never reads rows behind its range `break`
+    # (absorption.c:80-83), so a database it can process must not be refused at load.
     bad = synthetic.line_table("H2O", 1., 90., num_lines=20, seed=1, tips_range=(200, 350))
-    bad.local_iso_id[3] = 7                                   # no mass / TIPS row for iso 7
+    row = int(np.searchsorted(bad.nu, 60.))
+    bad.local_iso_id[row] = 7                                 # no mass / TIPS row for iso 7
+    hb = e.load(bad)
     with pytest.raises(EngineError, match="local_iso_id"):
-        e.load(bad)
+        e.compute(hb, 250., 1000., 1e-3, 1, 50, 10)          # row within v0-26 .. vn+26
+    reached = e.compute(hb, 250., 1000., 1e-3, 1, 20, 10)    # break before the bad row
+    good = bad.subset(np.arange(bad.num_lines) != row)
+    hg = e.load(good)
+    assert np.array_equal(reached, e.compute(hg, 250., 1000., 1e-3, 1, 20, 10))
+    with pytest.raises(EngineError, match="local_iso_id"):
+        e.compute(hb, 250., 1000., 1e-3, 40, 80, 10, range_policy="skip")
     k = e.compute(h, 250., 1000., 1e-3, 1, 50, 10)           # still usable afterwards
     assert k.shape == (1, 490) and k.any()
     e.close()
@@ -432,3 +443,148 @@ def test_row_copies_and_pinned_results():
     assert len(engine.pinned.idle) == idle - 1 and again.shape == (levels, 3, columns)
     block.free()
     engine.free(handle)
+
+
+def test_output_of_molecule_without_data_is_zeroed(small_database):
+    """No TIPS rows -> the reference returns the zeroed spectrum (absorption.c:41, :53-59): a
+    caller-supplied buffer must read zero too, on the host and in HBM, unless it accumulates."""
+    from pylbl_amd import Gas
+    from pylbl_amd.engine import DeviceSpectra
+    db, _ = small_database
+    gas = Gas(db, "N2O")
+    assert gas.molecule is None
+    grid = np.arange(1., 40., 0.1)
+    v0, vn, npv = synthetic.grid_arguments(grid)
+    n = (vn - v0)*npv
+    host = np.full((2, n), 5.)
+    gas.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-7, 3e-7], grid, out=host)
+    assert not host.any()
+    block = DeviceSpectra(gas.engine, 2, n)
+    gas.engine.lib.lbl_fill_zero(gas.engine.handle, block.pointer, 2, n, 0, 1)
+    filled = block.to_host()
+    assert not filled.any()
+    from pylbl_amd import synthetic as syn
+    other = Gas(syn.line_table("CO2", 1., 60., num_lines=100, seed=9, tips_range=(150, 400)), "CO2",
+                engine=gas.engine)
+    other.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-4, 3e-4], grid, out=block)
+    kept = block.to_host()
+    assert kept.any()
+    gas.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-7, 3e-7], grid, out=block,
+                                accumulate=True)
+    assert np.array_equal(block.to_host(), kept)            # nothing to add
+    gas.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-7, 3e-7], grid, out=block,
+                                asynchronous=True)
+    gas.engine.synchronize()
+    assert not block.to_host().any()
+    block.free()
+
+
+def test_asynchronous_pedestal_calls_into_one_buffer_are_ordered():
+    """Two asynchronous pedestal calls run on different lanes; when they write the same block
+    the later one must win, and to_host() must wait for whichever lane wrote last."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    a = e.load(synthetic.line_table("H2O", 1., 400., num_lines=30000, seed=71, tips_range=(150, 400)))
+    b = e.load(synthetic.line_table("CO2", 1., 400., num_lines=500, seed=72, tips_range=(150, 400)))
+    v0, vn, npv = 1, 361, 500
+    expect = e.compute(b, 250., 3e4, 3.6e-4, v0, vn, npv, remove_pedestal=True)
+    out = DeviceSpectra(e, 1, (vn - v0)*npv)
+    for _ in range(4):
+        e.compute(a, 250., 3e4, 5e-3, v0, vn, npv, remove_pedestal=True, out=out,
+                  asynchronous=True)        # long
+        e.compute(b, 250., 3e4, 3.6e-4, v0, vn, npv, remove_pedestal=True, out=out,
+                  asynchronous=True)        # short: would finish first if unordered
+        assert np.array_equal(out.to_host(), expect)
+    out.free()
+    e.close()
+
+
+def test_compat_entry_device_and_cache(tmp_path):
+    """The same-signature entry picks its GPU from LBL_DEVICE / the launcher's local rank,
+    re-reads a database file that changed under the same path (the reference re-reads it on
+    every call, absorption.c:44-73) and keeps a bounded number of molecules in HBM."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, time
+        import numpy as np
+        from ctypes import byref, c_int32
+        sys.path.insert(0, os.environ["LBL_TEST_ROOT"])
+        from pylbl_amd import engine, synthetic
+        from pylbl_amd.database import write_database
+        lib = engine.library()
+        device, resident = c_int32(-2), c_int32(-2)
+        lib.lbl_compat_state(byref(device), byref(resident))
+        assert (device.value, resident.value) == (-1, 0)
+        path = os.path.join(os.environ["LBL_TEST_TMP"], "lines.db")
+        formulas = ("H2O", "CO2", "O3")
+        def write(seed):
+            tables = [synthetic.line_table(f, 1., 90., num_lines=60, seed=seed + i,
+                                           tips_range=(150, 400)) for i, f in enumerate(formulas)]
+            write_database(path, tables)
+            return tables
+        def call(formula):
+            k = np.full(600, 3.)
+            rc = lib.absorption(9e4, 280., 1e-3, 1, 61, 10, k.ctypes.data, path.encode(),
+                                formula.encode(), 25, 0)
+            assert rc == 0
+            return k
+        write(100)
+        first = call("H2O")
+        lib.lbl_compat_state(byref(device), byref(resident))
+        assert device.value == int(os.environ["EXPECT_DEVICE"]), device.value
+        assert resident.value == 1
+        assert np.array_equal(call("H2O"), first)
+        call("CO2"); call("O3")
+        lib.lbl_compat_state(byref(device), byref(resident))
+        assert resident.value == 2, resident.value          # LBL_COMPAT_CACHE=2
+        assert np.array_equal(call("H2O"), first)          # evicted, read again: same answer
+        os.remove(path)
+        time.sleep(0.01)
+        write(200)                                          # same path, other lines
+        changed = call("H2O")
+        assert changed.any() and not np.array_equal(changed, first)
+        print("compat ok")
+    """)
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, expect in (({"LBL_DEVICE": "0"}, 0), ({"LOCAL_RANK": "5"}, 5 % 1), ({}, 0)):
+        env = {k: v for k, v in os.environ.items() if k not in ("LBL_DEVICE", "LOCAL_RANK")}
+        env.update(extra)
+        env.update({"LBL_COMPAT_CACHE": "2", "EXPECT_DEVICE": str(expect), "LBL_TEST_ROOT": root,
+                    "LBL_TEST_TMP": str(tmp_path)})
+        result = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                                env=env, timeout=300)
+        assert "compat ok" in result.stdout, result.stdout[-2000:] + result.stderr[-4000:]
+    # An index beyond the visible devices fails loudly (rc 1), it does not fall back.
+    env = dict(os.environ, LBL_DEVICE="99", LBL_TEST_ROOT=root, LBL_TEST_TMP=str(tmp_path))
+    bad = textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, os.environ["LBL_TEST_ROOT"])
+        from pylbl_amd import engine
+        lib = engine.library()
+        k = np.zeros(600)
+        path = os.path.join(os.environ["LBL_TEST_TMP"], "lines.db")
+        print("rc", lib.absorption(9e4, 280., 1e-3, 1, 61, 10, k.ctypes.data, path.encode(),
+                                   b"H2O", 25, 0))
+    """)
+    result = subprocess.run([sys.executable, "-c", bad], capture_output=True, text=True, env=env,
+                            timeout=300)
+    assert "rc 1" in result.stdout, result.stdout + result.stderr[-2000:]
+
+
+def test_grid_edited_in_place_is_uploaded_again(continuum_oracle):
+    """The device copy of the spectral grid is cached per array object; editing that array in
+    place between two calls must not leave the continuum on the old wavenumbers."""
+    from pylbl_amd import mt_ckd
+    continuum = mt_ckd.CarbonDioxideContinuum(device=0)
+    vmr = {"H2O": 6.6e-3, "CO2": 3.6e-4, "O2": 0.209, "N2": 0.78}
+    grid = np.arange(500., 900., 0.01)
+    first = np.array(continuum.spectra(288.99, 98388., vmr, grid))
+    grid += 700.                                            # same object, new contents
+    second = continuum.spectra(288.99, 98388., vmr, grid)
+    expect = continuum_oracle.continuum("CO2").spectra(288.99, 98388., vmr, grid)
+    np.testing.assert_allclose(second, expect, rtol=1e-6, atol=1e-300)
+    assert not np.array_equal(first, second)
