@@ -3,20 +3,28 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one batch: for every level of this rank's shard and
-every molecule of the workload, line-scalar prep + tile schedule + Voigt accumulate (+ the
-pedestal pre-pass when --pedestal) with the line tables already resident in HBM and the
-spectra left in HBM; with N > 1 the step ends with the RCCL gather of the level shards to
-rank 0.  Metric: line x gridpoint Voigt evaluations per second (BASELINE.json), counted in
-closed form as the reference's inner-loop iterations (sum of last-first+1, spectra.c:48-62).
+A step = one pass of the hot path over one batch: for every (level, molecule) unit of this
+rank (pylbl_amd.distributed.partition), line-scalar prep + tile schedule + Voigt accumulate
+(+ the pedestal pre-pass with --pedestal), line tables already resident in HBM, spectra left
+in HBM; with N > 1 the step ends by starting the collection of the spectra on rank 0 (one
+grouped send/recv over RCCL, pylbl_amd.distributed.ShardedLines), which runs beside the next
+step.  Metric: line x gridpoint Voigt evaluations per second (BASELINE.json), counted in closed
+form as the reference's inner-loop iterations (sum of last-first+1, spectra.c:48-62).
 
-Workload at N = 1 (default): the configuration BASELINE.json quotes its target on -- 1
-level, H2O + CO2, grid 1-5000 cm-1 at 0.001 cm-1 (5 M points), synthetic HITRAN-like line
-tables (no HITRAN database exists offline).  --config selects the other BASELINE configs.
-Weak scaling: every rank gets --levels-per-gpu levels (default 1) of a standard atmosphere.
+Workload at N = 1 (default): the configuration BASELINE.json quotes its target on -- 1 level,
+H2O + CO2, grid 1-5000 cm-1 at 0.001 cm-1 (5 M points), synthetic HITRAN-like line tables (no
+HITRAN database exists offline).  --config selects the other BASELINE configs.  Weak scaling:
+every rank gets --levels-per-gpu levels (default 1).
+
+Besides the contract's keys the line carries (N = 1): `roofline` (the resource that binds the
+dominant kernel: the fp64 vector ALU), `roofline_hbm_algorithmic` (SURVEY 8d's 24 B/eval figure,
+for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure what users run:
+`sustained`, `pedestal_option`, `standard_atmosphere_option`, `banded_table_option`,
+`small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -28,18 +36,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-FP64_VECTOR_PEAK_TFLOPS = 78.6
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
+SIMDS = 1024                # 256 CUs x 4
+BOOST_CLOCK_GHZ = 2.4
 BYTES_PER_EVAL = 24         # load dwno[i], load k[i], store k[i] (voigt.c:76,188)
 FLOPS_PER_EVAL = 7          # 5 common + 2 for the far-wing branch (>99 % of evals)
 
+EIGHT = ["H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2"]
 CONFIGS = {
-    # name: (molecules, v_lo, v_hi, dv, levels_total (None = per-gpu levels))
+    # name: (molecules, v_lo, v_hi, dv, levels of the BASELINE config)
     "0": (["CO2"], 500., 800., 0.1, 1),
     "1": (["H2O", "CO2"], 1., 5000., 0.01, 1),
     "target": (["H2O", "CO2"], 1., 5000., 0.001, 1),
-    "2": (["H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2"], 1., 5000., 0.001, 1),
+    "2": (EIGHT, 1., 5000., 0.001, 1),
     "3": (["H2O", "CO2", "O3"], 1., 3000., 0.001, 64),
-    "4": (["H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2"], 1., 5000., 0.0005, 256),
+    "4": (EIGHT, 1., 5000., 0.0005, 256),
 }
 
 
@@ -54,19 +65,23 @@ def parse():
                         help="atmosphere of multi-level runs (see atmosphere_for)")
     parser.add_argument("--pedestal", action="store_true",
                         help="remove_pedestal=True (the default through compute_absorption)")
+    parser.add_argument("--output", default="gas", choices=["gas", "total"],
+                        help="what a step leaves / collects: one spectrum per molecule, or "
+                             "n k summed over the molecules on the device")
     parser.add_argument("--line-scale", type=float, default=1.,
                         help="multiplies the HITRAN-like line counts")
+    parser.add_argument("--banded", action="store_true",
+                        help="banded line tables (same counts) instead of uniform ones")
     parser.add_argument("--points-per-lane", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-extras", action="store_true",
-                        help="only the timed steps: no CPU baseline, no far-field extra pass "
-                             "(what scripts/profile_bench.sh runs under rocprofv3)")
-    parser.add_argument("--extras", default="all", choices=["all", "none", "farfield", "continuum"],
-                        help="which untimed extra legs run after the timed steps "
-                             "(continuum = the continuum and cross-section slots)")
+                        help="only the timed steps (what scripts/profile_bench.sh profiles)")
+    parser.add_argument("--extras", default="all",
+                        help="comma list of untimed legs: all, none, or any of sustained, "
+                             "pedestal, atmosphere, banded, small, farfield, api, continuum")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
-                             "series (an algorithmic shortcut; not the default)")
+                             "series (an algorithmic shortcut; never the headline value)")
     parser.add_argument("--host-output", action="store_true",
                         help="copy every spectrum back to host memory inside the step "
                              "(PCIe-inclusive rate; never the headline value)")
@@ -76,8 +91,12 @@ def parse():
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
-    parser.add_argument("--cpu-sample-cm", type=float, default=3000.,
-                        help="width [cm-1] of the grid sample the CPU baseline is timed on")
+    parser.add_argument("--cpu-sample-cm", type=float, default=0.,
+                        help="width [cm-1] of the grid sample the CPU baseline is timed on "
+                             "(0 = the whole grid, ~22 s for the default workload)")
+    parser.add_argument("--cpu-workers", type=int, default=16,
+                        help="processes of cpu_baseline_parallel (16 = one GPU's share of the "
+                             "host on this pool; pass the host's core count to use them all)")
     return parser.parse_args()
 
 
@@ -104,15 +123,28 @@ def atmosphere_for(levels_total, profile):
     return synthetic.Atmos(p=p, t=t, vmr=vmr)
 
 
-def cpu_baseline(tables, atmos, v0, n_per_v, sample_cm, remove_pedestal):
-    """Times the CPU path on a bounded sample of the same workload (level 0, the first
-    `sample_cm` cm-1 of the grid, lines within reach of it): the reference's own compiled C
-    reading SQLite when oracle/_ref is present ("reference"), else our C restatement
-    ("port").  One thread, like the reference."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as handle:
+            for line in handle:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baselines (the only place bench.py touches oracle/)
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal):
+    """Times the CPU path on level 0 of the same workload (the whole grid unless --cpu-sample-cm
+    bounds it): the reference's own compiled C reading SQLite when oracle/_ref is present
+    ("reference"), else our C restatement ("port").  One thread, like the reference."""
     import tempfile
     from oracle import oracle
     from pylbl_amd.database import write_database
-    vn = v0 + int(sample_cm)
+    vn = vn_full if sample_cm <= 0 else min(vn_full, v0 + int(sample_cm))
     sample = [t.subset(t.nu <= vn + 26.) for t in tables]
     evals = 0
     kind = "reference" if oracle.have_reference() else "port"
@@ -124,10 +156,6 @@ def cpu_baseline(tables, atmos, v0, n_per_v, sample_cm, remove_pedestal):
             db = write_database(os.path.join(tmp, "sample.db"), sample)
         for t in sample:
             args = (atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], v0, vn, n_per_v)
-            start = time.perf_counter()
-            _, extras = oracle.absorption_port(t, *args, remove_pedestal=remove_pedestal)
-            port_seconds += time.perf_counter() - start
-            evals += extras["evals"]
             if kind == "reference":
                 start = time.perf_counter()
                 rc, _ = oracle.absorption_reference(db, t.formula, *args,
@@ -135,26 +163,98 @@ def cpu_baseline(tables, atmos, v0, n_per_v, sample_cm, remove_pedestal):
                 seconds += time.perf_counter() - start
                 if rc != 0:
                     raise RuntimeError("reference absorption() failed")
+                # The reference does not report its iteration count; it is closed form
+                # (window lengths, spectra.c:48-62), checked against the restatement's own
+                # counter by tests/test_host_logic.py.
+                evals += closed_form_evals(t, atmos.p[0], v0, vn, n_per_v)
+            else:
+                start = time.perf_counter()
+                _, extras = oracle.absorption_port(t, *args, remove_pedestal=remove_pedestal)
+                port_seconds += time.perf_counter() - start
+                evals += extras["evals"]
     if kind == "port":
         seconds = port_seconds
+    whole = vn == vn_full
     return {
         "value": evals/seconds, "unit": "evals/s", "cores": 1, "kind": kind,
-        "sample": f"level 0, {'+'.join(t.formula for t in sample)}, grid {v0}-{vn} cm-1 at "
+        "sample": f"level 0, {'+'.join(t.formula for t in sample)}, "
+                  f"{'the whole grid' if whole else 'grid sample'} {v0}-{vn} cm-1 at "
                   f"{1./n_per_v:g} cm-1, {sum(t.num_lines for t in sample)} lines, "
-                  f"{evals:.4g} evals in {seconds:.2f} s (SQLite read per call included, as "
-                  f"the reference does); C restatement on arrays: {evals/port_seconds:.4g} "
-                  f"evals/s",
+                  f"{evals:.4g} evals in {seconds:.2f} s"
+                  + (" (SQLite read per call included, as the reference does)"
+                     if kind == "reference" else ""),
         "cpu": cpu_model(), "host_cores": os.cpu_count(),
     }
 
 
+def closed_form_evals(table, pressure, v0, vn, n_per_v, cut_off=25):
+    """Sum over accepted lines of last-first+1 exactly as spectra.c:48-62 forms the window."""
+    n = (vn - v0)*n_per_v
+    accepted = np.ones(table.num_lines, bool)
+    outside = (table.nu > vn + cut_off + 1) | (table.nu < v0 - (cut_off + 1))
+    if outside.any():
+        accepted[np.argmax(outside):] = False           # absorption.c:80-83
+    centre = table.nu + (pressure*9.86923e-6)*table.delta_air
+    fl = np.floor(centre)
+    first = ((fl - cut_off - v0)*n_per_v).astype(np.int64)
+    last = ((fl + cut_off + 1 - v0)*n_per_v).astype(np.int64)
+    keep = accepted & (first < n)
+    first = np.maximum(first, 0)
+    last = np.minimum(last, n - 1)
+    length = np.where(keep & (last >= first), last - first + 1, 0)
+    return int(length.sum())
+
+
+def _cpu_chunk(job):
+    """Worker of cpu_baseline_parallel: the C restatement on one sub-grid of the sample."""
+    from oracle import oracle
+    table, t, p, x, v0, vn, n_per_v, remove_pedestal = job
+    _, extras = oracle.absorption_port(table, t, p, x, v0, vn, n_per_v,
+                                       remove_pedestal=remove_pedestal)
+    return extras["evals"]
+
+
+def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, workers):
+    """What a user could do with multiprocessing around the reference's Gas: independent
+    (molecule, sub-grid) units of the same grid farmed out over `workers` processes (our C
+    restatement on arrays; pedestal off, the units would not be independent with it)."""
+    import multiprocessing
+    vn = vn_full if sample_cm <= 0 else min(vn_full, v0 + int(sample_cm))
+    pieces = max(4*workers, 1)
+    edges = np.unique(np.linspace(v0, vn, pieces + 1).astype(int))
+    jobs = []
+    for t in tables:
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            near = t.subset((t.nu >= lo - 26.) & (t.nu <= hi + 26.))
+            jobs.append((near, atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], int(lo),
+                         int(hi), n_per_v, False))
+    jobs.sort(key=lambda job: -job[0].num_lines*(job[5] - job[4]))
+    context = multiprocessing.get_context("spawn")
+    with context.Pool(workers) as pool:
+        pool.map(_cpu_chunk, jobs[-workers:])          # start-up and library load, untimed
+        start = time.perf_counter()
+        evals = sum(pool.map(_cpu_chunk, jobs, chunksize=1))
+        seconds = time.perf_counter() - start
+    return {"value": evals/seconds, "unit": "evals/s", "cores": workers, "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": f"the grid {v0}-{vn} cm-1 cut into {len(jobs)} (molecule, sub-grid) "
+                      f"units over {workers} processes (--cpu-workers; the pool allots one GPU "
+                      f"16 of the host's {os.cpu_count()} hardware threads), {evals:.4g} evals "
+                      f"in {seconds:.2f} s"}
+
+
+# ---------------------------------------------------------------------------------------------
+# profiles/ look-ups (the PMC counters cannot be read from inside bench.py)
+# ---------------------------------------------------------------------------------------------
 def profiled_traffic(workload, kernel="accumulate_kernel"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 counter summary
     (profiles/*_summary.json, made by scripts/profile_bench.sh + summarize_profile.py: separate
     FETCH_SIZE / WRITE_SIZE passes, KiB units, reads doubled per the gfx950 correction) -- only
-    if that profile ran this same workload; the counters cannot be read from inside bench.py."""
+    if that profile ran this same workload."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")),
+                   key=os.path.getmtime, reverse=True)
+    for path in paths:
         try:
             with open(path) as handle:
                 summary = json.load(handle)
@@ -168,38 +268,124 @@ def profiled_traffic(workload, kernel="accumulate_kernel"):
     return None, None
 
 
-def _cpu_chunk(job):
-    """Worker of cpu_baseline_parallel: the C restatement on one sub-grid of the sample."""
-    from oracle import oracle
-    table, t, p, x, v0, vn, n_per_v, remove_pedestal = job
-    _, extras = oracle.absorption_port(table, t, p, x, v0, vn, n_per_v,
-                                       remove_pedestal=remove_pedestal)
-    return extras["evals"]
+def profiled_issue(workload):
+    """fp64 VALU wave-instructions per accumulate launch (and busy cycles, when collected) from
+    the newest profiles/*_valu_counters.json of this workload (scripts/profile_counters.sh)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_counters.json")),
+                   key=os.path.getmtime, reverse=True)
+    for path in paths:
+        try:
+            with open(path) as handle:
+                summary = json.load(handle)
+            if summary.get("workload") != workload:
+                continue
+            for name, entry in summary["kernels"].items():
+                if "accumulate_kernel" in name:
+                    c = entry["mean_per_launch"]
+                    fp64 = sum(c[x] for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                                              "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                    return {"fp64_wave_instructions_per_launch": fp64,
+                            "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                            "evals_per_launch": summary.get("evals_per_accumulate_launch"),
+                            "gui_active_cycles_per_launch": c.get("GRBM_GUI_ACTIVE"),
+                            "source": f"profiles/{os.path.basename(path)}"}
+        except (OSError, KeyError, TypeError, ValueError):
+            continue
+    return None
 
 
-def cpu_baseline_parallel(tables, atmos, v0, n_per_v, sample_cm, workers):
-    """What a user could do with multiprocessing around the reference's Gas: independent
-    (molecule, sub-grid) units of the same sample farmed out over `workers` processes
-    (our C restatement on arrays; pedestal off, the units would not be independent with it)."""
-    import multiprocessing
-    vn = v0 + int(sample_cm)
-    edges = np.linspace(v0, vn, workers + 1).astype(int)
-    jobs = []
-    for t in tables:
-        for lo, hi in zip(edges[:-1], edges[1:]):
-            if hi > lo:
-                near = t.subset((t.nu >= lo - 26.) & (t.nu <= hi + 26.))
-                jobs.append((near, atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], int(lo),
-                             int(hi), n_per_v, False))
-    context = multiprocessing.get_context("spawn")
-    with context.Pool(workers) as pool:
-        pool.map(_cpu_chunk, jobs[:workers])           # start-up and library load, untimed
+# ---------------------------------------------------------------------------------------------
+# Device legs
+# ---------------------------------------------------------------------------------------------
+def lines_leg(engine, handles, tables, t, p, vmr, grid_args, steps, remove_pedestal=False,
+              warmup=2, min_seconds=0., label=""):
+    """`steps` passes (at least min_seconds) of prep + schedule + accumulate (+ pedestal) for
+    every molecule over the given levels, spectra left in HBM; wall clock around a drained
+    engine.  Returns evals/s, ms per step, spectra (levels) per second."""
+    from pylbl_amd.engine import DeviceSpectra
+    v0, vn, n_per_v = grid_args
+    n = (vn - v0)*n_per_v
+    levels = len(t)
+    outs = [DeviceSpectra(engine, levels, n) for _ in handles]
+    evals = 0
+
+    def step(count=False):
+        total = 0
+        for handle, table, out in zip(handles, tables, outs):
+            result = engine.compute(handle, t, p, vmr[table.formula], v0, vn, n_per_v,
+                                    remove_pedestal=remove_pedestal, out=out, asynchronous=True,
+                                    want_evals=count)
+            if count:
+                total += result[1]
+        return total
+    evals = step(count=True)
+    for _ in range(max(warmup - 1, 0)):
+        step()
+    engine.synchronize()
+    done, elapsed = 0, 0.
+    start = time.perf_counter()
+    while True:
+        for _ in range(steps):
+            step()
+        engine.synchronize()
+        done += steps
+        elapsed = time.perf_counter() - start
+        if elapsed >= min_seconds:
+            break
+    for out in outs:
+        out.free()
+    return {"workload": label, "value": evals*done/elapsed, "unit": "evals/s",
+            "ms_per_step": elapsed/done*1e3, "spectra_per_s": levels*done/elapsed,
+            "steps": done, "evals_per_step": evals, "remove_pedestal": bool(remove_pedestal)}
+
+
+def api_leg(engine, tables, atmos, v_lo, v_hi, dv, device_step_ms, repeats=5):
+    """Wall clock of the call users make: Spectroscopy.compute_absorption() -- lines with the
+    pedestal removed + MT-CKD continua of the same gases, results delivered as host arrays (the
+    reference's contract) -- per output format, and the page-locked D2H rate it is bound by."""
+    from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic
+    from pylbl_amd.engine import DeviceSpectra
+    grid = np.arange(v_lo, v_hi, dv)
+    formulas = [t.formula for t in tables]
+    level = synthetic.Atmos(p=atmos.p[:1], t=atmos.t[:1],
+                            vmr={f: atmos.vmr[f][:1] for f in formulas})
+    try:
+        spec = Spectroscopy(level, grid, MemoryDatabase(tables), device=engine.device)
+        spec.compute_absorption(output_format="total")
+    except FileNotFoundError:       # no MT-CKD coefficient tables anywhere: lines only
+        spec = Spectroscopy(level, grid, MemoryDatabase(tables), continua_backend=None,
+                            device=engine.device)
+    # What the host link delivers into page-locked memory: one 40 MB-class copy, timed alone.
+    block = DeviceSpectra(engine, 1, grid.size)
+    target = engine.host_array((1, grid.size))
+    block.to_host_into(target)
+    start = time.perf_counter()
+    for _ in range(5):
+        block.to_host_into(target)
+    link_gbs = grid.size*8*5/(time.perf_counter() - start)/1e9
+    block.free()
+    out = {"workload": f"Spectroscopy.compute_absorption(): 1 level, {'+'.join(formulas)}, "
+                       f"{grid.size} points, lines (remove_pedestal as the reference defaults) + "
+                       f"continua, host arrays returned", "formats": {},
+           "d2h_pinned_gbs_measured": link_gbs}
+    for fmt, arrays in (("total", 1), ("gas", len(formulas)), ("all", 3*len(formulas))):
+        spec.compute_absorption(output_format=fmt)
         start = time.perf_counter()
-        evals = sum(pool.map(_cpu_chunk, jobs, chunksize=1))
-        seconds = time.perf_counter() - start
-    return {"value": evals/seconds, "unit": "evals/s", "cores": workers, "kind": "port",
-            "sample": f"same sample as cpu_baseline cut into {len(jobs)} (molecule, sub-grid) "
-                      f"units, {evals:.4g} evals in {seconds:.2f} s"}
+        for _ in range(repeats):
+            result = spec.compute_absorption(output_format=fmt)
+        seconds = (time.perf_counter() - start)/repeats
+        del result
+        delivered = arrays*grid.size*8
+        out["formats"][fmt] = {
+            "ms_per_call": seconds*1e3, "spectra_per_s": 1./seconds,
+            "bytes_delivered": delivered,
+            "roofline": {"bound": "pcie_d2h", "achieved": delivered/seconds/1e9,
+                         "peak": link_gbs, "unit": "GB/s",
+                         "frac": delivered/seconds/1e9/link_gbs}}
+    out["device_resident_step_ms"] = device_step_ms
+    out["total_vs_device_step"] = out["formats"]["total"]["ms_per_call"]/device_step_ms
+    return out
 
 
 def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
@@ -211,8 +397,7 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cp
     try:
         path = mt_ckd_data.default_path()
     except FileNotFoundError:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden",
-                            "mt_ckd_bands.npz")
+        path = os.path.join(ROOT, "tests", "golden", "mt_ckd_bands.npz")
         if not os.path.isfile(path):
             return None
     owners = []
@@ -244,12 +429,10 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cp
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
     block.free()
-    # Algorithmic bytes per launch: wavenumber in + extinction out per point and level, plus
-    # the extinction read back by the launches that add to it.
-    # cpu_baseline of this leg: the numpy restatement of the reference's path (oracle/, "port";
-    # the reference itself needs netCDF4/xarray) for the first level, one thread.
     cpu = None
     if with_cpu:
+        # The numpy restatement of the reference's path (oracle/, "port"; the reference itself
+        # needs netCDF4/xarray) for the first level, one thread.
         from oracle import mt_ckd_oracle
         tables = mt_ckd_oracle.load_tables(path)
         first = {formula: values[0] for formula, values in vmr.items()}
@@ -345,21 +528,16 @@ def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
     }
 
 
-def cpu_model():
-    try:
-        with open("/proc/cpuinfo") as handle:
-            for line in handle:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
 def main():
     args = parse()
     if args.no_extras:
         args.extras = "none"
+    wanted = set(args.extras.split(","))
+    every = "all" in wanted
+
+    def leg(name):
+        return every or name in wanted
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -380,18 +558,31 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from pylbl_amd import synthetic
+    from pylbl_amd import distributed, synthetic
     from pylbl_amd.engine import Engine
+    fixture = os.path.join(ROOT, "tests", "golden", "mt_ckd_bands.npz")
+    if os.path.isfile(fixture):
+        os.environ.setdefault("PYLBL_MT_CKD", fixture)      # continuum coefficients (api leg)
 
-    molecules, v_lo, v_hi, dv, config_levels = CONFIGS[args.config]
+    molecules, v_lo, v_hi, dv, _ = CONFIGS[args.config]
     grid_v0, grid_vn, n_per_v = synthetic.grid_arguments(np.asarray([v_lo, v_lo + dv, v_hi - dv]))
+    grid_args = (grid_v0, grid_vn, n_per_v)
     n = (grid_vn - grid_v0)*n_per_v
     levels_local = args.levels_per_gpu
     levels_total = levels_local*world
     atmos = atmosphere_for(levels_total, args.profile)
-    mine = slice(rank*levels_local, (rank + 1)*levels_local)
 
-    tables = [synthetic.line_table(f, v_lo, v_hi, scale=args.line_scale) for f in molecules]
+    def make_tables(banded):
+        out = []
+        for i, f in enumerate(molecules):
+            uniform = synthetic.line_table(f, v_lo, v_hi, scale=args.line_scale)
+            if banded:
+                out.append(synthetic.banded_line_table(f, v_lo, v_hi, num_lines=uniform.num_lines,
+                                                       bands=8, seed=41 + i))
+            else:
+                out.append(uniform)
+        return out
+    tables = make_tables(args.banded)
     engine = Engine(device_index)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
@@ -399,79 +590,59 @@ def main():
         engine.set_option("farfield", 1)
     if args.ablate:
         engine.set_option("ablate", args.ablate)
-    handles = [engine.load(t) for t in tables]
+    handles = {t.formula: engine.load(t) for t in tables}
 
-    # Spectra stay in HBM: [molecule, level, n] per rank (torch only owns the memory).  Two
-    # buffers alternate so that the gather of one step (N > 1) runs beside the next step.
-    spectra = [torch.empty((len(molecules), levels_local, n), dtype=torch.float64, device="cuda")
-               for _ in range(2 if world > 1 else 1)]
-    on_host = world > 1 and args.backend == "gloo"
-    gathered = [None, None]
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty_like(spectra[0], device="cpu" if on_host else "cuda")
-                     for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
-    counter = [0]
-    use_all_gather = [False]
-
-    class Slot(object):
-        def __init__(self, tensor):
-            self.pointer = tensor.data_ptr()
-            self.shape = tuple(tensor.shape)
-
-    # --host-output: page-locked host memory, what Gas/Spectroscopy hand their callers.
+    # The product path for any N: (level, molecule) units partitioned over the ranks, spectra
+    # written by the engine into torch-owned HBM, one grouped send/recv to rank 0 per step.
+    sharded = distributed.ShardedLines.for_engine(
+        engine, handles, grid_args, remove_pedestal=args.pedestal,
+        scale_density=(args.output == "total"), weights=[t.num_lines for t in tables])
+    vmr = {f: atmos.vmr[f] for f in molecules}
+    plan = distributed.partition(levels_total, [t.num_lines for t in tables], world)
     host_spectra = engine.host_array((len(molecules), levels_local, n)) if args.host_output \
         else None
+    pending = [None, None]
+    counter = [0]
 
-    def settle(which):
-        """Waits for the gather that last used buffer `which`."""
-        if pending[which] is not None:
-            pending[which].wait()
-            if not on_host:
-                torch.cuda.current_stream().synchronize()
-            pending[which] = None
-
-    def step(count_evals=False):
-        which = counter[0] % len(spectra)
-        counter[0] += 1
-        settle(which)
+    def count_evals():
+        """Closed-form evals of this rank's units (the engine's own count, one blocking pass)."""
         total = 0
-        for m, handle in enumerate(handles):
+        for m, levels in plan.by_molecule(rank).items():
             formula = molecules[m]
-            result = engine.compute(handle, atmos.t[mine], atmos.p[mine], atmos.vmr[formula][mine],
-                                    grid_v0, grid_vn, n_per_v, remove_pedestal=args.pedestal,
-                                    out=host_spectra[m] if args.host_output
-                                    else Slot(spectra[which][m]),
-                                    asynchronous=not args.host_output,
-                                    want_evals=count_evals)
-            if count_evals:
-                total += result[1]
-        if world > 1:
-            # The engine runs on its own streams: finish the spectra, then start the gather;
-            # it completes while the next step computes into the other buffer.
-            engine.synchronize()
-            source = spectra[which].cpu() if on_host else spectra[which]
-            if not use_all_gather[0]:
-                try:
-                    pending[which] = dist.gather(source, gathered[which], dst=0, async_op=True)
-                except (RuntimeError, NotImplementedError, ValueError):
-                    use_all_gather[0] = True    # backend without gather: every rank collects
-            if use_all_gather[0]:
-                if gathered[which] is None:
-                    gathered[which] = [torch.empty_like(source) for _ in range(world)]
-                pending[which] = dist.all_gather(gathered[which], source, async_op=True)
+            _, evals = engine.compute(handles[formula], atmos.t[levels], atmos.p[levels],
+                                      vmr[formula][levels], *grid_args,
+                                      remove_pedestal=args.pedestal, want_evals=True)
+            total += evals
         return total
 
+    def step():
+        which = counter[0] % 2
+        counter[0] += 1
+        if world > 1 and pending[which] is not None:
+            # The exchange that last read this pair of buffers.  (One rank: the engine's own
+            # streams order successive writes to a buffer, nothing to wait for.)
+            pending[which].wait()
+            pending[which] = None
+        if args.host_output:
+            for m, formula in enumerate(molecules):
+                engine.compute(handles[formula], atmos.t, atmos.p, vmr[formula], *grid_args,
+                               remove_pedestal=args.pedestal, out=host_spectra[m])
+            return
+        pending[which] = sharded.run(atmos.t, atmos.p, vmr, dst=0, output=args.output,
+                                     async_op=True)
+
     def fence():
-        settle(0)
-        settle(1)
+        for which in (0, 1):
+            if pending[which] is not None:
+                pending[which].wait()
+                pending[which] = None
         engine.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    evals_per_step_local = step(count_evals=True)
-    for _ in range(max(args.warmup - 1, 0)):
+    evals_per_step_local = count_evals()
+    for _ in range(max(args.warmup, 1)):
         step()
     fence()
     engine.set_option("timing", 1)
@@ -485,45 +656,8 @@ def main():
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
 
-    # Not part of `value`: the same steps with the optional far-field series switched on.
-    farfield_extra = None
-    if world == 1 and not args.farfield and not args.ablate and not args.host_output and \
-            args.extras in ("all", "farfield"):
-        engine.set_option("farfield", 1)
-        for _ in range(2):
-            step()
-        fence()
-        start = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        far_elapsed = time.perf_counter() - start
-        engine.set_option("farfield", 0)
-        farfield_extra = {
-            "value": evals_per_step_local*args.steps/far_elapsed, "unit": "evals/s",
-            "ms_per_step": far_elapsed/args.steps*1e3,
-            "note": "engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 tile "
-                    "half-widths away are summed as one power series per tile (truncation "
-                    "<= ~1.5e-11 relative); same closed-form eval count; opt-in, parity-tested "
-                    "at the same 1e-6 bar",
-        }
-
-    # Not part of `value` either: mechanism slot 1 (MT-CKD continua) for the same gases, levels
-    # and grid, written into the same kind of HBM block.
-    continuum_extra = None
-    if world == 1 and not args.ablate and not args.host_output and \
-            args.extras in ("all", "continuum"):
-        continuum_extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps,
-                                        not args.no_cpu_baseline)
-
-    cross_section_extra = None
-    if world == 1 and not args.ablate and not args.host_output and \
-            args.extras in ("all", "continuum"):
-        cross_section_extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps,
-                                                not args.no_cpu_baseline)
-
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
-                         device="cpu" if on_host else "cuda")
+                         device="cpu" if (world > 1 and args.backend == "gloo") else "cuda")
     if world > 1:
         worst = stats.clone()
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
@@ -534,85 +668,182 @@ def main():
     else:
         evals_per_step = float(evals_per_step_local)
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed/args.steps*1e3
         value = evals_per_step*args.steps/elapsed
         accumulate_ms = kernel_ms[2]/max(launches[2], 1)
         evals_per_launch = evals_per_step_local/max(launches[2]/args.steps, 1)
-        achieved = evals_per_launch*BYTES_PER_EVAL/(accumulate_ms*1e-3)/1e9
+        tflops = evals_per_launch*FLOPS_PER_EVAL/(accumulate_ms*1e-3)/1e12
+        algorithmic = evals_per_launch*BYTES_PER_EVAL/(accumulate_ms*1e-3)/1e9
+        workload = (f"BASELINE config '{args.config}': {levels_local} level(s) per GPU, "
+                    f"{'+'.join(molecules)}, grid {v_lo:g}-{v_hi:g} cm-1 at {dv:g} cm-1 "
+                    f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
+                    + (", far-field series on" if args.farfield else "")
+                    + (", banded tables" if args.banded else ""))
         line = {
-            "metric": "line\u00d7gridpoint Voigt evals/sec (whole job; per GPU: evals_per_s_per_gpu; spectra/sec: spectra_per_s)",
+            "metric": "line×gridpoint Voigt evals/sec (whole job; per GPU: evals_per_s_per_gpu; spectra/sec: spectra_per_s)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE config '{args.config}': {levels_local} level(s) per GPU, "
-                            f"{'+'.join(molecules)}, grid {v_lo:g}-{v_hi:g} cm-1 at {dv:g} cm-1 "
-                            f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
-                            + (", far-field series on" if args.farfield else ""),
+                "workload": workload,
                 "lines": {t.formula: t.num_lines for t in tables},
-                "levels_total": levels_total, "atmosphere": args.profile, "parallelism": f"levels sharded over {world} GPU(s)"
-                + (f", {args.backend} gather to rank 0 every step (overlapping the next step)"
-                   if world > 1 else ""),
+                "levels_total": levels_total, "atmosphere": args.profile,
+                "output": args.output,
+                "parallelism": f"(level, molecule) units over {world} GPU(s): "
+                               f"{plan.mode} sharded"
+                + (f", one grouped {args.backend} send/recv to rank 0 per step, overlapping the "
+                   f"next step" if world > 1 else ""),
             },
             "evals_per_step": evals_per_step,
             "evals_per_s_per_gpu": value/world,
             "spectra_per_s": levels_total*args.steps/elapsed,
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                "bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tflops/FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                 "kernel": "lbl::accumulate_kernel", "avg_launch_ms": accumulate_ms,
-                "launches_timed": launches[2],
-                "note": "achieved = 24 algorithmic bytes per eval (the reference's load v[i], "
-                        "load+store k[i]) x evals per launch / launch time; the kernel keeps "
-                        "partial sums in registers, so real HBM traffic is ~8 B per grid point "
-                        "and the binding resource is the fp64 vector ALU (see roofline_fp64)",
+                "launches_timed": launches[2], "flops_per_eval": FLOPS_PER_EVAL,
+                "evals_per_launch": evals_per_launch,
+                "note": "the kernel keeps partial sums in registers and writes k once, so HBM "
+                        "carries ~8 B per grid point (traffic, from the PMC counters) and the "
+                        "binding resource is the fp64 vector ALU: achieved = SURVEY 8(d)'s 7 "
+                        "algorithmic flops per eval (5 common + 2 far-wing incl. the divide) x "
+                        "evals per launch / mean launch time (HIP events on the engine's stream); "
+                        "peak = datasheet fp64 vector rate at 2.4 GHz",
             },
-            "roofline_fp64": {
-                "bound": "fp64 vector ALU", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "achieved": evals_per_launch*FLOPS_PER_EVAL/(accumulate_ms*1e-3)/1e12,
-                "frac": evals_per_launch*FLOPS_PER_EVAL/(accumulate_ms*1e-3)/1e12 /
-                        FP64_VECTOR_PEAK_TFLOPS,
-                "flops_per_eval": FLOPS_PER_EVAL,
+            "roofline_hbm_algorithmic": {
+                "bound": "hbm", "achieved": algorithmic, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": algorithmic/HBM_PEAK_GBS,
+                "note": "SURVEY 8(d) as written: 24 B per eval (the reference's load v[i], "
+                        "load+store k[i]) x evals / launch time.  These bytes never move here "
+                        "(register accumulation), so the 'fraction' exceeds 1 and is not a "
+                        "bandwidth; north_star's '>= 40 % of the HBM roofline' is 1.33e11 evals/s",
             },
             "kernel_ms_per_step": {
                 "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
                 "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
         }
+        traffic, source = profiled_traffic(workload)
+        if traffic is not None:
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_source"] = f"profiles/{source}"
+        issue = profiled_issue(workload)
+        if issue is not None and issue.get("evals_per_launch"):
+            per_eval = issue["fp64_wave_instructions_per_launch"]*64./issue["evals_per_launch"]
+            # One fp64 wave-instruction occupies a SIMD's issue port for 4 cycles (16 lanes/cycle).
+            ceiling = SIMDS*BOOST_CLOCK_GHZ*1e9/4.*64./per_eval
+            issue.update({
+                "fp64_wave_instructions_per_64_evals": per_eval,
+                "issue_ceiling_evals_per_s_at_2.4GHz": ceiling,
+                "frac_of_issue_ceiling_at_2.4GHz": evals_per_launch/(accumulate_ms*1e-3)/ceiling})
+            if issue.get("gui_active_cycles_per_launch"):
+                cycles = issue["gui_active_cycles_per_launch"]
+                per_simd = issue["fp64_wave_instructions_per_launch"]/SIMDS*4.
+                issue["frac_of_issue_slots_at_measured_clock"] = per_simd/cycles
+            line["roofline"]["issue"] = issue
         if args.pedestal:
             line["roofline"]["note"] += ("; remove_pedestal=True: calls alternate between engine "
                                          "lanes and their accumulate kernels overlap in time, so "
                                          "avg_launch_ms is not the duration of a kernel running "
                                          "alone (see the plain run for that)")
-        if farfield_extra is not None:
-            line["farfield_option"] = farfield_extra
-        if cross_section_extra is not None:
-            line["cross_section_slot"] = cross_section_extra
-            traffic, source = profiled_traffic(line["config"]["workload"], "xsec_interp_kernel")
-            if traffic is not None:
-                cross_section_extra["roofline"]["traffic"] = traffic
-                cross_section_extra["roofline"]["traffic_source"] = f"profiles/{source}"
-        if continuum_extra is not None:
-            line["continuum_slot"] = continuum_extra
-            traffic, source = profiled_traffic(line["config"]["workload"], "continuum_interp_kernel")
-            if traffic is not None:
-                continuum_extra["roofline"]["traffic"] = traffic
-                continuum_extra["roofline"]["traffic_source"] = f"profiles/{source}"
         if args.host_output:
             line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
-        traffic, source = profiled_traffic(line["config"]["workload"])
-        if traffic is not None:
-            line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_source"] = f"profiles/{source}"
         if args.ablate:
             line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
-        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
-            line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, n_per_v,
+
+    # ---- untimed legs, one GPU only -----------------------------------------------------------
+    plain = world == 1 and not args.ablate and not args.host_output
+    if plain and rank == 0 and args.extras != "none":
+        handle_list = [handles[f] for f in molecules]
+        t1, p1 = atmos.t[:1], atmos.p[:1]
+        vmr1 = {f: atmos.vmr[f][:1] for f in molecules}
+        if leg("sustained"):
+            line["sustained"] = lines_leg(
+                engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+                remove_pedestal=args.pedestal, min_seconds=2.,
+                label="the timed step repeated for >= 2 s (clocks at their sustained level)")
+        if leg("pedestal") and not args.pedestal:
+            line["pedestal_option"] = lines_leg(
+                engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+                remove_pedestal=True,
+                label="same workload with remove_pedestal=True (the default through "
+                      "compute_absorption, spectroscopy.py:163-164)")
+        if leg("atmosphere"):
+            standard = synthetic.standard_atmosphere(8)
+            line["standard_atmosphere_option"] = lines_leg(
+                engine, handle_list, tables, standard.t, standard.p,
+                {f: standard.vmr[f] for f in molecules}, grid_args, max(args.steps//4, 2),
+                remove_pedestal=True,
+                label="8 standard-atmosphere levels (1013 hPa ... 0.1 hPa) in one batched call "
+                      "per molecule, remove_pedestal=True")
+        if leg("banded") and not args.banded:
+            banded_tables = make_tables(True)
+            banded_handles = [engine.load(t) for t in banded_tables]
+            line["banded_table_option"] = lines_leg(
+                engine, banded_handles, banded_tables, t1, p1, vmr1, grid_args, args.steps,
+                remove_pedestal=True,
+                label="same line counts clustered in 8 Gaussian bands per molecule "
+                      "(synthetic.banded_line_table), remove_pedestal=True")
+            for h in banded_handles:
+                engine.free(h)
+        if leg("small") and args.config == "target":
+            small = {}
+            for name in ("0", "1"):
+                mols, lo, hi, step_cm, _ = CONFIGS[name]
+                ga = synthetic.grid_arguments(np.asarray([lo, lo + step_cm, hi - step_cm]))
+                small_tables = [synthetic.line_table(f, lo, hi) for f in mols]
+                small_handles = [engine.load(t) for t in small_tables]
+                small[f"config{name}"] = lines_leg(
+                    engine, small_handles, small_tables, t1, p1,
+                    {f: atmos.vmr[f][:1] for f in mols}, ga, 50, min_seconds=0.3,
+                    label=f"BASELINE configs[{name}]: {'+'.join(mols)}, {lo:g}-{hi:g} cm-1 at "
+                          f"{step_cm:g} cm-1")
+                for h in small_handles:
+                    engine.free(h)
+            line["small_grid_options"] = small
+        if leg("farfield") and not args.farfield:
+            engine.set_option("farfield", 1)
+            far = {}
+            for ped in (False, True):
+                far["remove_pedestal" if ped else "plain"] = lines_leg(
+                    engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+                    remove_pedestal=ped)
+            engine.set_option("farfield", 0)
+            far["note"] = ("engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 "
+                           "tile half-widths away are summed as one power series per tile "
+                           "(truncation <= ~1.5e-11 relative); same closed-form eval count; "
+                           "parity-tested at the same 1e-6 bar; what Spectroscopy(farfield=True) "
+                           "runs; never the headline value")
+            line["farfield_option"] = far
+        if leg("api"):
+            line["api_call"] = api_leg(engine, tables, atmos, v_lo, v_hi, dv,
+                                       line.get("pedestal_option", line)["ms_per_step"])
+        if leg("continuum"):
+            mine = slice(0, levels_local)
+            extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps,
+                                  not args.no_cpu_baseline)
+            if extra is not None:
+                line["continuum_slot"] = extra
+                traffic, source = profiled_traffic(workload, "continuum_interp_kernel")
+                if traffic is not None:
+                    extra["roofline"]["traffic"] = traffic
+                    extra["roofline"]["traffic_source"] = f"profiles/{source}"
+            extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps,
+                                      not args.no_cpu_baseline)
+            line["cross_section_slot"] = extra
+            traffic, source = profiled_traffic(workload, "xsec_interp_kernel")
+            if traffic is not None:
+                extra["roofline"]["traffic"] = traffic
+                extra["roofline"]["traffic_source"] = f"profiles/{source}"
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.extras != "none":
+            line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, grid_vn, n_per_v,
                                                 args.cpu_sample_cm, args.pedestal)
-            workers = min(16, os.cpu_count() or 1)
+            workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
             if workers > 1:
                 line["cpu_baseline_parallel"] = cpu_baseline_parallel(
-                    tables, atmos, grid_v0, n_per_v, args.cpu_sample_cm, workers)
+                    tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -7,7 +7,8 @@ Names mirror ``pyLBL/__init__.py:1-5``: ``Gas``, ``Database``, ``molecular_lines
 GPU; the first ``Gas``/``Engine``/continuum/``CrossSection`` does, and fails loudly if the HIP
 library or the device is missing.
 """
-from .database import Database, LineTable, TotalPartitionFunction, write_database
+from .database import Database, LineTable, MemoryDatabase, TotalPartitionFunction, \
+                      write_database
 from .errors import AliasNotFoundError, CrossSectionNotFoundError, EngineError, \
                     IsotopologuesNotFoundError, TipsDataNotFoundError, TransitionsNotFoundError
 from .engine import DeviceSpectra, Engine, default_engine
@@ -16,7 +17,7 @@ from .gas_optics import Gas
 from .plugins import continua, cross_sections, models, molecular_lines, register
 from .spectroscopy import Atmosphere, Spectroscopy, number_density
 
-__all__ = ["Gas", "CrossSection", "Database", "LineTable", "TotalPartitionFunction", "write_database",
+__all__ = ["Gas", "CrossSection", "Database", "MemoryDatabase", "LineTable", "TotalPartitionFunction", "write_database",
            "Engine", "DeviceSpectra", "default_engine", "Spectroscopy", "Atmosphere",
            "number_density", "molecular_lines", "continua", "cross_sections", "models",
            "register", "AliasNotFoundError", "CrossSectionNotFoundError", "EngineError", "IsotopologuesNotFoundError",

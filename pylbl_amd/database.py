@@ -216,6 +216,47 @@ class Database(object):
         return GasData(table.formula, list(table.mass), transitions, tips)
 
 
+class MemoryDatabase(object):
+    """The read surface of ``Database`` over LineTables already in memory (synthetic tables, or
+    a line list the caller assembled): ``path`` is None, nothing is written to disk.  What the
+    lines backend and ``Spectroscopy`` need -- ``molecules()``, ``line_table(name)``,
+    ``gas(name)``, ``tips(name)`` -- behaves like the file-backed class, including
+    AliasNotFoundError for an unknown name."""
+    def __init__(self, tables, aliases=None):
+        self.path = None
+        self.tables = {table.formula: table for table in tables}
+        self.aliases = {}
+        for formula, names in (aliases or {}).items():
+            for name in names:
+                self.aliases[name] = formula
+
+    def molecules(self):
+        return list(self.tables)
+
+    def line_table(self, name):
+        formula = self.aliases.get(name, name)
+        if formula not in self.tables:
+            raise AliasNotFoundError(f"{name} not found in database.")
+        table = self.tables[formula]
+        if table.tips_data is None or np.size(table.tips_data) == 0:
+            raise TipsDataNotFoundError(f"tips data not found for molecule {name}.")
+        if table.num_lines == 0:
+            raise TransitionsNotFoundError(f"transitions not found for molecule {name}.")
+        return table
+
+    def tips(self, name):
+        table = self.line_table(name)
+        return table.tips_temperature, table.tips_data
+
+    def gas(self, name):
+        table = self.line_table(name)
+        transitions = np.rec.fromarrays(
+            [getattr(table, x) for x in LINE_COLUMNS] + [table.local_iso_id],
+            names=list(LINE_COLUMNS) + ["local_iso_id"])
+        tips = TotalPartitionFunction(name, table.tips_temperature, table.tips_data)
+        return GasData(table.formula, list(table.mass), transitions, tips)
+
+
 # Exact DDL of the reference's schema (pyLBL/database.py:418-486 as emitted by
 # SQLAlchemy's create_all); note the misspelt "molcule_id" column of artscrossfit.
 SCHEMA = """

@@ -1,15 +1,28 @@
-"""Multi-GPU form of the lines path: one process per GPU, atmospheric levels sharded.
+"""Multi-GPU form of the lines path: one process per GPU, (level, molecule) units sharded.
 
 The reference is serial (no threads, no MPI): ``Spectroscopy.compute_absorption`` loops
 molecule-outer / level-inner and carries no state between iterations
-(pyLBL/spectroscopy.py:166-191; every ``absorption()`` call starts from a memset,
-pyLBL/c_lib/absorption.c:41).  (level, molecule) units are therefore independent and the
-only exchange the path ever needs is the final gather of the level shards.
+(pyLBL/spectroscopy.py:166,179; every ``absorption()`` call starts from a memset,
+pyLBL/c_lib/absorption.c:41).  (level, molecule) units are therefore independent, and the only
+exchange the path ever needs is the final collection of the spectra on one rank -- plus, when
+the molecules of ONE level are spread over several GPUs and the caller wants the sum over gases
+(spectroscopy.py:225-234), one sum-reduction.
 
-Layout: contiguous blocks of levels per rank, all molecules of a level on the same rank (so
-per-gas / total reductions stay local), line tables replicated on every GPU.  The gather is
-one ``torch.distributed`` collective -- RCCL over xGMI on GPUs (backend "nccl"), gloo in the
-CPU tests.
+Partition (``partition``):
+  * levels >= ranks: contiguous blocks of whole levels per rank, all molecules of a level on the
+    same rank, so the per-gas / total sums stay on the device that computed them (BASELINE
+    configs 4 and 5: 64 and 256 levels over 8 GPUs);
+  * levels < ranks: the level-major list of (level, molecule) units is cut into contiguous runs
+    of near-equal weight (weight = transitions of the molecule), so that e.g. one level x eight
+    molecules (BASELINE config 3) occupies eight GPUs instead of one.  A single unit is never
+    split: one spectrum's grid stays on one GPU.
+Line tables are replicated on every GPU (<= 1.4 M transitions, ~90 MB).
+
+Exchange: one grouped point-to-point gather per call (every rank sends its blocks straight
+into their final place on the destination: `torch.distributed.batch_isend_irecv`, i.e. one
+ncclGroup of send/recv over xGMI, no padding and no concatenation copy), or one `reduce` for
+the cross-rank total.  Backend "nccl" is RCCL on ROCm (tensors stay in HBM); with "gloo" (CPU
+tests, or rehearsing several ranks on one GPU) the blocks travel through host memory.
 """
 import numpy as np
 
@@ -27,8 +40,69 @@ def shard_sizes(n_levels, world):
             for r in range(world)]
 
 
+class Partition(object):
+    """Which (level, molecule) units each rank computes.
+
+    Attributes:
+        mode: "levels" (whole levels per rank) or "units" (levels < ranks).
+        units: units[rank] = list of (level, molecule index), level-major.
+    """
+    def __init__(self, mode, units, n_levels, n_molecules):
+        self.mode, self.units = mode, units
+        self.n_levels, self.n_molecules = n_levels, n_molecules
+
+    def levels_of(self, rank):
+        """Sorted levels rank touches."""
+        return sorted({level for level, _ in self.units[rank]})
+
+    def by_molecule(self, rank):
+        """{molecule index: [levels]} of the rank's units, levels ascending."""
+        out = {}
+        for level, molecule in self.units[rank]:
+            out.setdefault(molecule, []).append(level)
+        return out
+
+
+def partition(n_levels, weights, world):
+    """Splits n_levels x len(weights) units over `world` ranks (see the module docstring).
+
+    Args:
+        weights: Relative cost of one level of each molecule (e.g. its number of transitions).
+    """
+    n_levels, world = int(n_levels), int(world)
+    weights = [max(float(w), 1e-9) for w in weights]
+    n_molecules = len(weights)
+    if n_levels >= world or n_molecules <= 1:
+        units = []
+        for rank in range(world):
+            mine = level_shard(n_levels, rank, world)
+            units.append([(level, m) for level in range(mine.start, mine.stop)
+                          for m in range(n_molecules)])
+        return Partition("levels", units, n_levels, n_molecules)
+    # Fewer levels than ranks: contiguous runs of the level-major unit list, cut where the
+    # running weight (taken at each unit's midpoint) crosses a multiple of total/world.
+    flat = [(level, m) for level in range(n_levels) for m in range(n_molecules)]
+    total = n_levels*sum(weights)
+    units = [[] for _ in range(world)]
+    running = 0.
+    for level, m in flat:
+        middle = running + 0.5*weights[m]
+        rank = min(int(middle*world/total), world - 1)
+        units[rank].append((level, m))
+        running += weights[m]
+    return Partition("units", units, n_levels, n_molecules)
+
+
+def _group_info(group):
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1, None
+    return dist.get_rank(group), dist.get_world_size(group), dist.get_backend(group)
+
+
 def gather_levels(local, n_levels, dst=0, group=None):
-    """Gathers per-rank blocks of levels (leading dimension) onto rank `dst`.
+    """Gathers per-rank blocks of levels (leading dimension) onto rank `dst` with one padded
+    gather / all-gather collective.
 
     Args:
         local: torch tensor [levels_local, ...] (CUDA with the nccl backend, CPU with gloo).
@@ -66,23 +140,67 @@ def gather_levels(local, n_levels, dst=0, group=None):
     return torch.cat([pieces[r][:sizes[r]] for r in range(world)], dim=0)
 
 
+class Pending(object):
+    """An exchange in flight: wait() returns what run() would have returned."""
+    def __init__(self, requests, finish, on_device, flush=None):
+        self.requests, self.finish, self.on_device = requests, finish, on_device
+        self.flush = flush
+        self.result = None
+        self.done = False
+
+    def wait(self):
+        if not self.done:
+            if self.flush is not None:
+                self.flush()
+            for request in self.requests:
+                request.wait()
+            if self.on_device:
+                import torch
+                # nccl work objects only order the *current torch stream* behind the transfer;
+                # the engine computes on its own streams, so settle the device side here.
+                torch.cuda.current_stream().synchronize()
+            self.result = self.finish()
+            self.done = True
+        return self.result
+
+
 class ShardedLines(object):
     """Lines spectra of a whole atmosphere over the ranks of a process group.
 
     Args:
-        compute: Callable (formula, temperature[L], pressure[L], vmr[L]) -> tensor [L, n] on
-                 this rank's device: the per-rank engine call.  Supplied by the caller so the
-                 sharding / gather logic is independent of the device (see ``for_engine``).
+        compute: Callable (formula, temperature[L'], pressure[L'], vmr[L'], out, accumulate):
+                 fills (or, with accumulate, adds to) the tensor ``out`` [L', n] on this rank's
+                 device with the spectra of those levels.  Supplied by the caller so that the
+                 sharding / exchange logic is independent of the device (see ``for_engine``).
+        molecules: Formulae, in the order results are reported.
+        n: Points per spectrum.
+        weights: Relative cost per molecule (default: equal); only used when levels < ranks.
+        device: torch device of the per-rank blocks ("cpu" in the gloo tests).
+        flush: Callable that returns once everything `compute` queued has finished (the
+               engine's synchronize); None if `compute` is synchronous.
     """
-    def __init__(self, compute, group=None):
+    def __init__(self, compute, molecules, n, weights=None, group=None, device="cpu",
+                 flush=None):
         self.compute = compute
+        self.molecules = list(molecules)
+        self.n = int(n)
+        self.weights = list(weights) if weights is not None else [1.]*len(self.molecules)
         self.group = group
+        self.device = device
+        self.flush = flush
+        self._buffers = {}
+        self._turn = 0
 
     @classmethod
     def for_engine(cls, engine, handles, grid_args, remove_pedestal=False, scale_density=False,
-                   group=None):
-        """Per-rank compute on an MI355X: spectra are written by the engine straight into a
-        torch CUDA tensor (torch only owns the memory and runs the collective)."""
+                   range_policy="reference", weights=None, group=None):
+        """Per-rank compute on an MI355X: the engine writes spectra straight into torch CUDA
+        tensors (torch only owns the memory and runs the exchange).
+
+        Args:
+            handles: {formula: engine molecule handle} (insertion order = reporting order).
+            grid_args: (v0, vn, n_per_v) as pyLBL/c_lib/gas_optics.py:61-63 derives them.
+        """
         import torch
         v0, vn, n_per_v = grid_args
         n = (vn - v0)*n_per_v
@@ -91,33 +209,185 @@ class ShardedLines(object):
             def __init__(self, tensor):
                 self.pointer, self.shape = tensor.data_ptr(), tuple(tensor.shape)
 
-        def compute(formula, temperature, pressure, vmr):
-            out = torch.empty((len(temperature), n), dtype=torch.float64,
-                              device=torch.device("cuda", engine.device))
+        def compute(formula, temperature, pressure, vmr, out, accumulate):
             if len(temperature):
                 engine.compute(handles[formula], temperature, pressure, vmr, v0, vn, n_per_v,
                                remove_pedestal=remove_pedestal, scale_density=scale_density,
-                               out=Slot(out))
-            return out
-        return cls(compute, group=group)
+                               range_policy=range_policy, out=Slot(out), accumulate=accumulate,
+                               asynchronous=True)
+        return cls(compute, list(handles), n, weights=weights, group=group,
+                   device=torch.device("cuda", engine.device), flush=engine.synchronize)
 
-    def run(self, temperature, pressure, vmr, dst=0):
-        """Args: temperature[L], pressure[L]; vmr: dict formula -> [L].  Every rank passes the
-        full atmosphere and computes only its own block of levels.
+    # -- buffers -----------------------------------------------------------------------------
+    def _buffer(self, name, shape, zero=False):
+        """Per-rank blocks are kept between calls, two of each so that an exchange still in
+        flight (async_op) is not overwritten by the next call."""
+        import torch
+        key = (name, self._turn % 2, tuple(shape))
+        tensor = self._buffers.get(key)
+        if tensor is None:
+            tensor = torch.empty(shape, dtype=torch.float64, device=self.device)
+            self._buffers[key] = tensor
+        if zero:
+            self._zero(tensor)
+        return tensor
 
-        Returns dict formula -> tensor [L, n] on rank `dst` (every rank if dst is None)."""
+    def _zero(self, tensor):
+        """torch queues the fill on its own stream; the engine computes on others, so the fill
+        has to have happened before `compute` is handed the block."""
+        tensor.zero_()
+        if tensor.is_cuda:
+            import torch
+            torch.cuda.current_stream(tensor.device).synchronize()
+
+    # -- the call ----------------------------------------------------------------------------
+    def run(self, temperature, pressure, vmr, dst=0, output="gas", async_op=False):
+        """Every rank passes the full atmosphere and computes only its own units.
+
+        Args:
+            temperature, pressure: [L]; vmr: dict formula -> [L].
+            dst: Destination rank, or None: every rank gets the result.
+            output: "gas": dict formula -> tensor [L, n]; "total": tensor [L, n], the sum over
+                    the molecules (meaningful with scale_density: n k summed over gases,
+                    pyLBL/spectroscopy.py:225-234), reduced on the device before it travels.
+            async_op: Return a Pending; the exchange runs beside whatever is queued next.
+
+        Returns:
+            On rank `dst` (every rank if dst is None) the result, elsewhere None (dict of None
+            for "gas"); or a Pending that yields it.
+        """
+        import torch
         import torch.distributed as dist
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-        temperature = np.asarray(temperature, dtype=np.float64)
-        pressure = np.asarray(pressure, dtype=np.float64)
-        mine = level_shard(temperature.size, rank, world)
-        out = {}
-        for formula, x in vmr.items():
-            local = self.compute(formula, temperature[mine], pressure[mine],
-                                 np.asarray(x, dtype=np.float64)[mine])
-            if world == 1:
-                out[formula] = local
+        rank, world, backend = _group_info(self.group)
+        temperature = np.ascontiguousarray(temperature, dtype=np.float64)
+        pressure = np.ascontiguousarray(pressure, dtype=np.float64)
+        x = {f: np.ascontiguousarray(vmr[f], dtype=np.float64) for f in self.molecules}
+        n_levels, n, m_count = temperature.size, self.n, len(self.molecules)
+        plan = partition(n_levels, self.weights, world)
+        mine = plan.by_molecule(rank)
+        my_levels = plan.levels_of(rank)
+        row = {level: i for i, level in enumerate(my_levels)}
+        self._turn += 1
+        on_device = str(self.device) != "cpu"
+        through_host = on_device and world > 1 and backend != "nccl"
+
+        # 1. compute this rank's units into its blocks
+        if output == "total":
+            # One [levels touched, n] block; every molecule adds to the rows of its levels.
+            block = self._buffer("total", (len(my_levels), n))
+            first = True
+            for m, levels in sorted(mine.items()):
+                rows = [row[level] for level in levels]
+                lo, hi = rows[0], rows[-1] + 1      # contiguous: units are level-major runs
+                assert rows == list(range(lo, hi))
+                if lo > 0 or hi < len(my_levels):
+                    # This molecule covers only part of the block (unit mode): make sure the
+                    # rows it skips are defined before anything adds to them.
+                    if first:
+                        self._zero(block)
+                    self.compute(self.molecules[m], temperature[levels], pressure[levels],
+                                 x[self.molecules[m]][levels], block[lo:hi], True)
+                else:
+                    self.compute(self.molecules[m], temperature[levels], pressure[levels],
+                                 x[self.molecules[m]][levels], block, not first)
+                first = False
+            if first and len(my_levels):
+                self._zero(block)
+            blocks = {None: block}
+        else:
+            # One contiguous [levels of this molecule, n] block per molecule.
+            blocks = {}
+            for m, levels in sorted(mine.items()):
+                blocks[m] = self._buffer(("gas", m), (len(levels), n))
+                self.compute(self.molecules[m], temperature[levels], pressure[levels],
+                             x[self.molecules[m]][levels], blocks[m], False)
+        # 2. one rank: done (with async_op the kernels stay queued until wait())
+        if world == 1:
+            if output == "total":
+                result = blocks[None]
             else:
-                out[formula] = gather_levels(local, temperature.size, dst=dst, group=self.group)
-        return out
+                result = {f: blocks[m] for m, f in enumerate(self.molecules)}
+            if async_op:
+                return Pending([], lambda: result, False, flush=self.flush)
+            if self.flush is not None:
+                self.flush()
+            return result
+        if self.flush is not None:
+            self.flush()
+
+        if through_host:
+            blocks = {key: value.cpu() for key, value in blocks.items()}
+        where = "cpu" if (through_host or not on_device) else self.device
+
+        # 3. exchange
+        receivers = range(world) if dst is None else (dst,)
+        i_receive = rank in receivers
+        if output == "total" and plan.mode == "units":
+            # The molecules of one level sit on several ranks: a real sum over ranks.
+            partial = torch.zeros((n_levels, n), dtype=torch.float64, device=where)
+            for i, level in enumerate(my_levels):
+                partial[level] = blocks[None][i]
+            if dst is None:
+                work = dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
+            else:
+                work = dist.reduce(partial, dst=dst, op=dist.ReduceOp.SUM, group=self.group,
+                                   async_op=True)
+            finish = (lambda: partial) if i_receive else (lambda: None)
+            pending = Pending([work], finish, where != "cpu")
+            return pending if async_op else pending.wait()
+
+        # Grouped point-to-point gather: every block goes straight into its final place.
+        if output == "total":
+            final = torch.empty((n_levels, n), dtype=torch.float64, device=where) \
+                if i_receive else None
+            pieces = lambda r: [(None, plan.levels_of(r))]                      # noqa: E731
+            place = lambda key, levels: final[levels[0]:levels[-1] + 1]          # noqa: E731
+        else:
+            final = torch.empty((m_count, n_levels, n), dtype=torch.float64, device=where) \
+                if i_receive else None
+            pieces = lambda r: sorted(plan.by_molecule(r).items())              # noqa: E731
+            place = lambda key, levels: final[key, levels[0]:levels[-1] + 1]     # noqa: E731
+        ops = []
+        for receiver in receivers:
+            if receiver == rank:
+                for sender in range(world):
+                    for key, levels in pieces(sender):
+                        if not levels:
+                            continue
+                        if sender == rank:
+                            place(key, levels).copy_(blocks[key])
+                        else:
+                            ops.append(dist.P2POp(dist.irecv, place(key, levels), sender,
+                                                  self.group))
+            else:
+                for key, levels in pieces(rank):
+                    if levels:
+                        ops.append(dist.P2POp(dist.isend, blocks[key], receiver, self.group))
+        requests = dist.batch_isend_irecv(ops) if ops else []
+
+        def finish():
+            if not i_receive:
+                return None if output == "total" else {f: None for f in self.molecules}
+            if output == "total":
+                return final
+            return {f: final[m] for m, f in enumerate(self.molecules)}
+        pending = Pending(requests, finish, where != "cpu")
+        return pending if async_op else pending.wait()
+
+
+def gather_arrays(local, n_levels, dst=0, group=None):
+    """Collects host arrays [levels_local, ...] of a level-sharded call (``level_shard``) on
+    rank `dst` (every rank if dst is None): what ``Spectroscopy(group=...)`` uses for its
+    result arrays, which live in host memory by the reference's contract.  With the nccl
+    backend the blocks are staged through HBM, with gloo they travel as they are."""
+    import torch
+    import torch.distributed as dist
+    rank, world, backend = _group_info(group)
+    if world == 1:
+        return local
+    tensor = torch.from_numpy(np.ascontiguousarray(local))
+    if backend == "nccl":
+        tensor = tensor.cuda()
+    out = gather_levels(tensor, n_levels, dst=dst, group=group)
+    return None if out is None else out.cpu().numpy()

@@ -47,6 +47,35 @@ class BandDescriptor(Structure):
 _library = None
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels ship their own
+    libamdhip64.so.7 (same SONAME as /opt/rocm's): when torch is imported first, this library
+    binds to torch's copy and all is well; the other way round torch finds the system runtime
+    already resident beside its own HSA libraries and sees no GPU.  So when a ROCm torch is
+    installed but not imported yet, its runtime is loaded here first (no torch import: only the
+    shared object), which makes the order irrelevant."""
+    import importlib.util
+    import os
+    import sys
+    from ctypes import RTLD_GLOBAL
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for location in spec.submodule_search_locations:
+        candidate = os.path.join(location, "lib", "libamdhip64.so")
+        if os.path.exists(candidate):
+            try:
+                CDLL(candidate, mode=RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def library():
     """Loads liblbl_amd.so (once) and declares the argument types of every entry point."""
     global _library
@@ -61,6 +90,7 @@ def library():
             raise EngineError(
                 f"{LIBRARY_PATH} is missing and could not be built ({error}); build it with "
                 "`python -m pylbl_amd.build` (there is no CPU fallback).")
+    _preload_hip_runtime()
     lib = CDLL(str(LIBRARY_PATH))
     f64p, i32p, i64p = POINTER(c_double), POINTER(c_int32), POINTER(c_int64)
     lib.lbl_engine_create.argtypes = [c_int32, POINTER(c_void_p)]

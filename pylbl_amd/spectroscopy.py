@@ -139,7 +139,16 @@ class Spectroscopy(object):
     Attributes mirror pyLBL/spectroscopy.py:72-86.
     """
     def __init__(self, atmosphere, grid, database, mapping=None, lines_backend="mi355x",
-                 continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0):
+                 continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0,
+                 group=None, gather_to=0):
+        """Args beyond the reference's (pyLBL/spectroscopy.py:88-118):
+            device: GPU index of this process.
+            group: None: this process computes every level.  True (the default process group)
+                   or a torch.distributed ProcessGroup: one process per GPU, each computes a
+                   contiguous block of levels (all gases and mechanisms of a level on the same
+                   GPU, pylbl_amd.distributed.level_shard) and compute_absorption collects the
+                   result on rank `gather_to` (None: on every rank); the other ranks get None.
+        """
         self.atmosphere = Atmosphere(atmosphere, mapping=mapping)
         # A private copy: the grid's device copy is cached per array object, and the lines
         # path reads (v0, vn, n_per_v) off it on every call -- a caller editing its own array
@@ -156,6 +165,8 @@ class Spectroscopy(object):
             else cross_sections[cross_sections_backend]
         self.cache = {}
         self.device = device
+        self.group = group
+        self.gather_to = gather_to
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
@@ -194,15 +205,47 @@ class Spectroscopy(object):
         temperature = self.atmosphere.temperature.ravel()
         pressure = self.atmosphere.pressure.ravel()
         shape = list(self.atmosphere.temperature.shape)
-        levels = temperature.size
         if remove_pedestal is None:
             remove_pedestal = self.continua_backend == "mt_ckd"
+        # Every gas at every level, the dictionary the continua read (spectroscopy.py:173).
+        mole_fractions = {name: x.ravel() for name, x in self.atmosphere.gases.items()}
+        mode = output_format if output_format in ("all", "gas") else "total"
+        columns = self.grid.size
+        if self.group is None:
+            flat = self._compute_levels(temperature, pressure, mole_fractions, mode,
+                                        remove_pedestal, range_policy)
+        else:
+            # One process per GPU: this rank's block of levels, then one collection per array.
+            from . import distributed
+            group = None if self.group is True else self.group
+            rank, world, _ = distributed._group_info(group)
+            mine = distributed.level_shard(temperature.size, rank, world)
+            local = self._compute_levels(
+                temperature[mine], pressure[mine], {k: v[mine] for k, v in mole_fractions.items()},
+                mode, remove_pedestal, range_policy)
+            flat = {name: distributed.gather_arrays(values, temperature.size, self.gather_to,
+                                                    group) for name, values in local.items()}
+            if any(values is None for values in flat.values()):
+                return None
+        tail = [len(MECHANISMS), columns] if mode == "all" else [columns]
+        return self._create_output_dataset(
+            {name: values.reshape(shape + tail) for name, values in flat.items()}, output_format)
+
+    def _compute_levels(self, temperature, pressure, mole_fractions, mode, remove_pedestal,
+                        range_policy):
+        """The three mechanism slots for a flat list of levels: {variable name: array with the
+        levels as leading dimension} ("total" under mode "total")."""
+        levels = temperature.size
         v0, vn, n_per_v = grid_arguments(self.grid)
         n = (vn - v0)*n_per_v
         columns = self.grid.size
-        mode = output_format if output_format in ("all", "gas") else "total"
-        # Every gas at every level, the dictionary the continua read (spectroscopy.py:173).
-        mole_fractions = {name: x.ravel() for name, x in self.atmosphere.gases.items()}
+        if levels == 0:
+            # A rank without levels (fewer levels than GPUs): empty blocks of the right shape.
+            if mode == "total":
+                return {"total": np.zeros((0, columns))}
+            tail = (len(MECHANISMS), columns) if mode == "all" else (columns,)
+            return {"{}_absorption".format(name): np.zeros((0,) + tail)
+                    for name in self.atmosphere.gases}
         in_hbm = levels*n*8 <= self.device_output_limit
         engine = None
 
@@ -297,8 +340,7 @@ class Spectroscopy(object):
                 values = np.zeros((levels, columns))
             for block in blocks.values():           # host blocks of the too-large case
                 values += block
-            return self._create_output_dataset(
-                {"total": values.reshape(shape + [columns])}, output_format)
+            return {"total": values}
         beta = {}
         for name in self.atmosphere.gases:
             varname = "{}_absorption".format(name)
@@ -309,15 +351,15 @@ class Spectroscopy(object):
                     for slot in range(len(MECHANISMS)):
                         if (name, slot) in blocks:
                             values[:, slot, :] = blocks[(name, slot)]
-                beta[varname] = values.reshape(self.output.dim_sizes)
+                beta[varname] = values
             else:
                 if values is None:
                     values = np.zeros((levels, columns))
                     for slot in range(len(MECHANISMS)):
                         if (name, slot) in blocks:
                             values += blocks[(name, slot)]
-                beta[varname] = values.reshape(shape + [columns])
-        return self._create_output_dataset(beta, output_format)
+                beta[varname] = values
+        return beta
 
     def _create_output_dataset(self, absorption, output_format):
         dims = list(self.output.dims)

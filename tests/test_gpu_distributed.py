@@ -1,0 +1,73 @@
+"""The multi-GPU product path (pylbl_amd.distributed.ShardedLines.for_engine) on a real GPU:
+at world size 1 in this process, and as two ranks that share GPU 0 and exchange over gloo
+(an 8-GPU node is not available to the tests; the partition and exchange code is the same
+that bench.py --gpus N runs over RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pylbl_amd import distributed, synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("output", ["gas", "total"])
+def test_for_engine_single_rank_against_oracle(oracle, output):
+    from pylbl_amd.engine import Engine
+    engine = Engine(0)
+    formulas = ("H2O", "CO2")
+    tables = {f: synthetic.line_table(f, 600., 700., num_lines=1500, seed=11 + i)
+              for i, f in enumerate(formulas)}
+    handles = {f: engine.load(tables[f]) for f in formulas}
+    atmos = synthetic.fixture_atmosphere()
+    v0, vn, npv = 610, 650, 500
+    vmr = {f: atmos.vmr[f] for f in formulas}
+    for ped in (False, True):
+        sharded = distributed.ShardedLines.for_engine(engine, handles, (v0, vn, npv),
+                                                      remove_pedestal=ped,
+                                                      scale_density=(output == "total"))
+        out = sharded.run(atmos.t, atmos.p, vmr, output=output)
+        expect = {f: np.asarray([oracle.absorption_port(tables[f], atmos.t[i], atmos.p[i],
+                                                        vmr[f][i], v0, vn, npv,
+                                                        remove_pedestal=ped)[0]
+                                 for i in range(4)]) for f in formulas}
+        if output == "total":
+            kb = 1.38064852e-23
+            total = sum(expect[f]*(atmos.p*vmr[f]/(kb*atmos.t))[:, None] for f in formulas)
+            got = out.cpu().numpy()
+            assert np.max(np.abs(got - total)/np.max(total, axis=1, keepdims=True)) <= 1e-6
+        else:
+            for f in formulas:
+                got = out[f].cpu().numpy()
+                scale = np.max(expect[f], axis=1, keepdims=True)
+                assert np.max(np.abs(got - expect[f])/scale) <= 1e-6
+    engine.close()
+
+
+@pytest.mark.parametrize("n_levels,output", [(5, "gas"), (1, "gas"), (1, "total"), (4, "total")])
+def test_two_ranks_share_one_gpu(n_levels, output):
+    """Levels >= ranks shards levels; one level shards its three molecules over the two ranks
+    (and the total then needs the cross-rank sum)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(n_levels),
+             output], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for rank, proc in enumerate(procs):
+        try:
+            out, err = proc.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for other in procs:
+                other.kill()
+            raise
+        assert proc.returncode == 0 and f"rank {rank} ok" in out, out + err[-3000:]

@@ -209,3 +209,15 @@ def test_atmosphere_from_plain_arrays():
         assert np.array_equal(atm.temperature, atmos.t) and set(atm.gases) == set(atmos.vmr)
     with pytest.raises(ValueError):
         Atmosphere({"p": atmos.p, "t": atmos.t, "vmr": {"H2O": atmos.vmr["H2O"][:2]}})
+
+
+def test_bench_closed_form_eval_count_matches_oracle(oracle):
+    """bench.py counts the reference's inner-loop iterations in closed form (the compiled
+    reference does not report them); same number as the restatement's own counter, with
+    clipped windows, lines left and right of the grid and the range `break`."""
+    import bench
+    for seed, (lo, hi, v0, vn, npv) in enumerate([(1., 200., 1, 150, 7), (30., 400., 60, 90, 100),
+                                                  (1., 90., 40, 80, 10), (100., 130., 100, 131, 3)]):
+        table = synthetic.line_table("CO2", lo, hi, num_lines=400, seed=seed, tips_range=(150, 400))
+        _, extras = oracle.absorption_port(table, 250., 5.e4, 3.6e-4, v0, vn, npv)
+        assert bench.closed_form_evals(table, 5.e4, v0, vn, npv) == extras["evals"]
