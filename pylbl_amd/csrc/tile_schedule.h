@@ -157,6 +157,11 @@ __global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict
     if (s.hi < s.lo) s.hi = s.lo;
     s.a1 = min(max(s.a1, s.lo), s.hi);
     s.a2 = min(max(s.a2, s.a1), s.hi);
+    // Normally every line that may have its core in the tile also covers it completely
+    // (cores reach ~1 cm-1, windows 25); with a tiny cut-off the clipping ranges can hold such
+    // lines too, and the accumulate kernel then takes them through its core path.
+    s.clip_core = (s.c1 < s.a1 && s.a1 > s.lo) || (s.c2 > s.a2 && s.a2 < s.hi) ? 1 : 0;
+    s.pad[0] = s.pad[1] = s.pad[2] = 0;
     s.c1 = min(max(s.c1, s.a1), s.a2);
     s.c2 = min(max(s.c2, s.c1), s.a2);
     // Far-field split (farfield.h): lines at least kFarRatio half-widths from the tile
