@@ -299,7 +299,7 @@ def profiled_issue(workload):
 # Device legs
 # ---------------------------------------------------------------------------------------------
 def lines_leg(engine, handles, tables, t, p, vmr, grid_args, steps, remove_pedestal=False,
-              warmup=2, min_seconds=0., label=""):
+              warmup=2, min_seconds=0., label="", ring=1):
     """`steps` passes (at least min_seconds) of prep + schedule + accumulate (+ pedestal) for
     every molecule over the given levels, spectra left in HBM; wall clock around a drained
     engine.  Returns evals/s, ms per step, spectra (levels) per second."""
@@ -307,12 +307,17 @@ def lines_leg(engine, handles, tables, t, p, vmr, grid_args, steps, remove_pedes
     v0, vn, n_per_v = grid_args
     n = (vn - v0)*n_per_v
     levels = len(t)
-    outs = [DeviceSpectra(engine, levels, n) for _ in handles]
+    # `ring` sets of output blocks: successive steps write different memory, so the engine may
+    # keep several calls in flight (it orders calls that write the same block).
+    outs = [DeviceSpectra(engine, levels, n) for _ in range(ring) for _ in handles]
     evals = 0
+    turn = [0]
 
     def step(count=False):
         total = 0
-        for handle, table, out in zip(handles, tables, outs):
+        first = (turn[0] % ring)*len(handles)
+        turn[0] += 1
+        for handle, table, out in zip(handles, tables, outs[first:first + len(handles)]):
             result = engine.compute(handle, t, p, vmr[table.formula], v0, vn, n_per_v,
                                     remove_pedestal=remove_pedestal, out=out, asynchronous=True,
                                     want_evals=count)
@@ -645,7 +650,9 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     fence()
-    engine.set_option("timing", 1)
+    # HIP events around the accumulate launches only (option value 2): events between all five
+    # kernels of a call keep them from running back to back.
+    engine.set_option("timing", 2)
     engine.timing(reset=True)
     fence()
     start = time.perf_counter()
@@ -796,9 +803,10 @@ def main():
                 small_handles = [engine.load(t) for t in small_tables]
                 small[f"config{name}"] = lines_leg(
                     engine, small_handles, small_tables, t1, p1,
-                    {f: atmos.vmr[f][:1] for f in mols}, ga, 50, min_seconds=0.3,
+                    {f: atmos.vmr[f][:1] for f in mols}, ga, 50, min_seconds=0.3, ring=4,
                     label=f"BASELINE configs[{name}]: {'+'.join(mols)}, {lo:g}-{hi:g} cm-1 at "
-                          f"{step_cm:g} cm-1")
+                          f"{step_cm:g} cm-1; throughput of asynchronous calls into a ring of 4 "
+                          f"output blocks")
                 for h in small_handles:
                     engine.free(h)
             line["small_grid_options"] = small

@@ -50,6 +50,10 @@ extern "C" {
 #define LBL_SCALE_DENSITY   4   /* multiply by number density P x /(kb T): the lines slot of
                                    Spectroscopy.compute_absorption (spectroscopy.py:181-191) */
 #define LBL_ACCUMULATE      8   /* add into k instead of overwriting it                     */
+#define LBL_FARFIELD       16   /* this call: lines at least 4 tile half-widths away (and beyond
+                                   every line core) enter through one power series per tile
+                                   instead of point by point -- truncation <= ~1.5e-11 relative,
+                                   3-4x faster at 0.001 cm-1 (same as option "farfield" = 1)  */
 
 typedef struct lbl_engine lbl_engine;
 

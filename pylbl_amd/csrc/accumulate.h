@@ -64,12 +64,10 @@ __host__ __device__ inline void tile_bounds(const Tiling & t, int tile, int n_pe
     if (i1 > n - 1) i1 = n - 1;
 }
 
-struct alignas(16) TileSchedule
+struct alignas(32) TileSchedule
 {
     int lo, a1, c1, c2, a2, hi;
     int f1, f2;         // [a1,f1) and [f2,a2): far enough for the series of farfield.h
-    int clip_core;      // 1: lines of [lo,a1) / [a2,hi) may have their core in the tile (tiny cut-offs)
-    int pad[3];
 };
 
 // Centre of a tile in wavenumber: the expansion point of the far-field series.
@@ -175,15 +173,12 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 // One line that may clip the tile or have its core in it, row by row (64 points each).
 // Per row the decisions are wave-uniform: skip (outside the window), Lorentz (whole row in
 // the far wing), or core.  In a core row every lane applies the reference's chain on
-// xi = (v-nu')*repwid (voigt.c:76-84).  Most core rows lie wholly in one region -- the w4
-// region 1 (voigt.c:95-96; at tropospheric pressure y >= 8.425 and region 1 reaches the line
-// centre) or the far wing -- and then only that one formula is evaluated, without selects;
-// mixed rows evaluate what their lanes need, and only lanes closer to the centre than xlim1
-// call wells_inner().
+// xi = (v-nu')*repwid (voigt.c:76-84): region 0 and w4 region 1 (voigt.c:95-96) are
+// evaluated inline; only lanes closer to the centre than xlim1 call wells_inner().
 template <int P>
-__device__ __forceinline__ void core_line(const LineWing & l, const LineCore & c,
-                                          int i0, int i1, int lane,
-                                          const double (&v)[P], double (&acc)[P])
+__device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
+                                             int i0, int i1, int lane,
+                                             const double (&v)[P], double (&acc)[P])
 {
     if (l.last < i0 || l.first > i1)
     {
@@ -204,7 +199,8 @@ __device__ __forceinline__ void core_line(const LineWing & l, const LineCore & c
         {
             continue;
         }
-        const bool clipped = l.first > r0 || l.last < r1;       // wave-uniform
+        const int i = r0 + lane;
+        const bool inside = (i >= l.first) && (i <= l.last);
         const double d = v[p] - l.centre;
         double value;
         if (c.core_last < r0 || c.core_first > r1)
@@ -219,185 +215,71 @@ __device__ __forceinline__ void core_line(const LineWing & l, const LineCore & c
             const double xq = abx*abx;
             const bool far = abx >= c.xlim0;
             const bool mid = !far && abx >= c.xlim1;
-            if (__all(mid))
+            value = 0.;
+            if (__any(far))
+            {
+                const double wing = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                value = far ? wing : value;
+            }
+            if (__any(mid))
             {
                 // voigt.c:95-96: buf = rsqrpi/(d0 + xq(d2 + xq)) * y * (a0 + xq)
-                value = r1_scale*(a0 + xq)*rcp_newton(__builtin_fma(xq, d2 + xq, d0));
+                const double w4 = r1_scale*(a0 + xq)*
+                                  rcp_newton(__builtin_fma(xq, d2 + xq, d0));
+                value = mid ? w4 : value;
             }
-            else if (__all(far))
+            if (!far && !mid)
             {
-                value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-            }
-            else
-            {
-                // Lanes in different regions.  Regions 0 and 1 are both rational in xq with the
-                // common factor rsqrpi*y (voigt.c:82, :95-96): one reciprocal serves both.
-                const double num = far ? 1. : a0 + xq;
-                const double den = far ? xq + yq : __builtin_fma(xq, d2 + xq, d0);
-                value = r1_scale*num*rcp_newton(den);
-                if (!far && !mid)
-                {
-                    value = c.amp*wells_inner(xi, c.y);
-                }
+                value = c.amp*wells_inner(xi, c.y);
             }
         }
-        if (clipped)
-        {
-            const int i = r0 + lane;
-            value = (i >= l.first && i <= l.last) ? value : 0.;
-        }
-        acc[p] += value;
+        acc[p] += inside ? value : 0.;
     }
 }
 
-// Index ranges of lines, walked as one list.
-template <int N>
-struct LineList
+// Up to five index ranges of lines in general position, walked as one list; records are
+// fetched two lines at a time so that the scalar-load latency is paid once per pair.
+struct GeneralList
 {
-    int begin[N];
-    int count[N];
-    __device__ __forceinline__ int total() const
-    {
-        int t = 0;
-#pragma unroll
-        for (int r = 0; r < N; ++r) t += count[r];
-        return t;
-    }
-    __device__ __forceinline__ int index(int k) const
-    {
-#pragma unroll
-        for (int r = 0; r < N - 1; ++r)
-        {
-            if (k < count[r]) return begin[r] + k;
-            k -= count[r];
-        }
-        return begin[N - 1] + k;
-    }
+    int begin[5];
+    int count[5];
 };
 
-// Lines that may have their core in the tile; records are fetched two lines at a time so that
-// the scalar-load latency is paid once per pair.
-template <int P, int N>
-__device__ __forceinline__ void core_ranges(const LineWing * __restrict__ wing,
-                                            const LineCore * __restrict__ core,
-                                            const LineList<N> & g, int i0, int i1, int lane,
-                                            const double (&v)[P], double (&acc)[P])
+__device__ __forceinline__ int general_index(const GeneralList & g, int k)
 {
-    const int total = g.total();
+    if (k < g.count[0]) return g.begin[0] + k;
+    k -= g.count[0];
+    if (k < g.count[1]) return g.begin[1] + k;
+    k -= g.count[1];
+    if (k < g.count[2]) return g.begin[2] + k;
+    k -= g.count[2];
+    if (k < g.count[3]) return g.begin[3] + k;
+    k -= g.count[3];
+    return g.begin[4] + k;
+}
+
+template <int P>
+__device__ __forceinline__ void general_ranges(const LineWing * __restrict__ wing,
+                                               const LineCore * __restrict__ core,
+                                               const GeneralList & g, int i0, int i1, int lane,
+                                               const double (&v)[P], double (&acc)[P])
+{
+    const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
     int k = 0;
     for (; k + 2 <= total; k += 2)
     {
-        const int ja = g.index(k), jb = g.index(k + 1);
+        const int ja = general_index(g, k), jb = general_index(g, k + 1);
         const LineWing la = wing[ja], lb = wing[jb];
         const LineCore ca = core[ja], cb = core[jb];
-        core_line<P>(la, ca, i0, i1, lane, v, acc);
-        core_line<P>(lb, cb, i0, i1, lane, v, acc);
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
+        general_line<P>(lb, cb, i0, i1, lane, v, acc);
     }
     if (k < total)
     {
-        const int ja = g.index(k);
+        const int ja = general_index(g, k);
         const LineWing la = wing[ja];
         const LineCore ca = core[ja];
-        core_line<P>(la, ca, i0, i1, lane, v, acc);
-    }
-}
-
-// One far-wing line with a window that cuts the tile, row by row (the exception path of
-// wing_ranges below).
-template <int P>
-__device__ __forceinline__ void wing_line(const LineWing & l, int i0, int i1, int lane,
-                                          const double (&v)[P], double (&acc)[P])
-{
-    if (l.last < i0 || l.first > i1)
-    {
-        return;
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-    {
-        const int r0 = i0 + p*64;
-        const int r1 = r0 + 63;
-        if (l.last < r0 || l.first > r1)
-        {
-            continue;
-        }
-        const double d = v[p] - l.centre;
-        double value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-        if (l.first > r0 || l.last < r1)
-        {
-            const int i = r0 + lane;
-            value = (i >= l.first && i <= l.last) ? value : 0.;
-        }
-        acc[p] += value;
-    }
-}
-
-// Far-wing lines in general position: windows that begin or end inside the tile (they do so on
-// integer wavenumbers, spectra.c:48-62, so neighbours in the sorted table nearly always share
-// the same cut) and the 0-3 left-over lines of each fast range.  Eight at a time: when all eight
-// reach the tile and share one clipped window [s, e] they take lorentz_eight() with wave-uniform
-// row decisions (whole row / masked row / no row); otherwise, and for the last few, one by one.
-template <int P, int N>
-__device__ __forceinline__ void wing_ranges(const LineWing * __restrict__ wing,
-                                            const LineList<N> & g, int i0, int i1, int lane,
-                                            const double (&v)[P], double (&acc)[P])
-{
-    const int total = g.total();
-    int k = 0;
-    for (; k + 8 <= total; k += 8)
-    {
-        WingTerm l[8];
-        int s = 0, e = 0;
-        bool uniform = true;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-        {
-            const LineWing w = wing[g.index(k + j)];
-            const int sj = max(w.first, i0), ej = min(w.last, i1);
-            if (j == 0) { s = sj; e = ej; }
-            uniform = uniform && sj == s && ej == e;
-            l[j] = WingTerm{w.centre, w.g2, w.bl};
-        }
-        if (uniform)
-        {
-            if (s > e)
-            {
-                continue;       // none of the eight reaches the tile
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-            {
-                const int r0 = i0 + p*64;
-                const int r1 = r0 + 63;
-                if (e < r0 || s > r1)
-                {
-                    continue;
-                }
-                if (s <= r0 && e >= r1)
-                {
-                    acc[p] = lorentz_eight(v[p], l, acc[p]);
-                }
-                else
-                {
-                    const double value = lorentz_eight(v[p], l, 0.);
-                    const int i = r0 + lane;
-                    acc[p] += (i >= s && i <= e) ? value : 0.;
-                }
-            }
-        }
-        else
-        {
-            for (int j = 0; j < 8; ++j)
-            {
-                const LineWing w = wing[g.index(k + j)];
-                wing_line<P>(w, i0, i1, lane, v, acc);
-            }
-        }
-    }
-    for (; k < total; ++k)
-    {
-        const LineWing w = wing[g.index(k)];
-        wing_line<P>(w, i0, i1, lane, v, acc);
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
     }
 }
 
@@ -446,44 +328,32 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     // This wavefront's share of each of the five cut-point ranges: the item's part of the
     // range, quartered.
     const int piece = item.part*4 + wave, pieces = item.parts*4;
-    int lo0, lo1, hi0, hi1, c0, c1, fa0, fa1, fb0, fb1;
-    share_of(sc.lo, sc.a1, piece, pieces, 1, lo0, lo1);
-    share_of(sc.c1, sc.c2, piece, pieces, 1, c0, c1);
-    share_of(sc.a2, sc.hi, piece, pieces, 1, hi0, hi1);
+    GeneralList g;
+    int fa0, fa1, fb0, fb1, e;
+    share_of(sc.lo, sc.a1, piece, pieces, 1, g.begin[0], e);
+    g.count[0] = e - g.begin[0];
+    share_of(sc.c1, sc.c2, piece, pieces, 1, g.begin[1], e);
+    g.count[1] = e - g.begin[1];
+    share_of(sc.a2, sc.hi, piece, pieces, 1, g.begin[2], e);
+    g.count[2] = e - g.begin[2];
     // [a1,f1) and [f2,a2) are summed by the far-field series (empty when that is off).
     share_of(sc.f1, sc.c1, piece, pieces, 4, fa0, fa1);
     share_of(sc.c2, sc.f2, piece, pieces, 4, fb0, fb1);
-    // Far-wing lines in general position: the clipping ranges (unless a tiny cut-off puts
-    // line cores into them) and the left-over lines of the far-wing ranges (fewer than four
-    // each).  Lines that may have their core in the tile: [c1,c2) (+ the clipping ranges then).
-    const bool clip_core = sc.clip_core != 0;
-    LineList<4> wings;
-    wings.begin[0] = lo0;
-    wings.count[0] = clip_core ? 0 : lo1 - lo0;
-    wings.begin[1] = hi0;
-    wings.count[1] = clip_core ? 0 : hi1 - hi0;
-    wings.begin[2] = fa0 + ((fa1 - fa0) & ~3);
-    wings.count[2] = (fa1 - fa0) & 3;
-    wings.begin[3] = fb0 + ((fb1 - fb0) & ~3);
-    wings.count[3] = (fb1 - fb0) & 3;
-    LineList<3> cores;
-    cores.begin[0] = c0;
-    cores.count[0] = c1 - c0;
-    cores.begin[1] = lo0;
-    cores.count[1] = clip_core ? lo1 - lo0 : 0;
-    cores.begin[2] = hi0;
-    cores.count[2] = clip_core ? hi1 - hi0 : 0;
-    if (a.ablate & 4) { wings.count[0] = 0; wings.count[1] = 0; }   // diagnostics: no clipping lines
-    if (a.ablate & 8) { wings.count[2] = 0; wings.count[3] = 0; }   // ... no left-overs of the fast ranges
-    if (a.ablate & 16) { cores.count[0] = 0; }                      // ... no core lines
+    // Left-over lines of the far-wing ranges (fewer than four each) take the general path.
+    g.begin[3] = fa0 + ((fa1 - fa0) & ~3);
+    g.count[3] = (fa1 - fa0) & 3;
+    g.begin[4] = fb0 + ((fb1 - fb0) & ~3);
+    g.count[4] = (fb1 - fb0) & 3;
+    if (a.ablate & 4) { g.count[0] = 0; g.count[2] = 0; }     // diagnostics: no clipping lines
+    if (a.ablate & 8) { g.count[3] = 0; g.count[4] = 0; }     // ... no left-overs of the fast ranges
+    if (a.ablate & 16) { g.count[1] = 0; }                    // ... no core lines
     if (!(a.ablate & 2))
     {
         fast_ranges<P>(wing, fa0, fa1, fb0, fb1, v, acc);
     }
     if (!(a.ablate & 1))
     {
-        wing_ranges<P, 4>(wing, wings, i0, i1, lane, v, acc);
-        core_ranges<P, 3>(wing, core, cores, i0, i1, lane, v, acc);
+        general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
     }
 
 #pragma unroll

@@ -146,6 +146,7 @@ struct Lane
     hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
     hipEvent_t finished = nullptr;  // end of the last call that wrote device output on this lane
     const char * out_begin = nullptr, * out_end = nullptr;     // ... and where it wrote
+    bool used = false;              // something was queued here since lane 0 last joined it
     bool levels_in_flight = false;
     DeviceBuffer<LineWing> wing;
     DeviceBuffer<LineCore> core;
@@ -218,19 +219,27 @@ struct LevelFeed
     DeviceBuffer<Level> levels;
     Level * pinned = nullptr;
     size_t pinned_capacity = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;      // last kernel of the last call (the destructor waits for it)
+    hipEvent_t copied = nullptr;    // last copy out of the pinned block
     bool in_flight = false;
 
+    // The host may refill the pinned block once the copy that read it has run; everything on the
+    // device side is ordered by the stream.
     void wait()
     {
-        if (in_flight) HIP_TRY(hipEventSynchronize(done));
+        if (in_flight) HIP_TRY(hipEventSynchronize(copied));
         in_flight = false;
+    }
+    void copied_on(hipStream_t stream)
+    {
+        if (copied == nullptr) HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(copied, stream));
+        in_flight = true;
     }
     void mark(hipStream_t stream)
     {
         if (done == nullptr) HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(done, stream));
-        in_flight = true;
     }
     void reserve_pinned(size_t count)
     {
@@ -244,6 +253,7 @@ struct LevelFeed
     ~LevelFeed()
     {
         if (done != nullptr) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); }
+        if (copied != nullptr) { (void)hipEventSynchronize(copied); (void)hipEventDestroy(copied); }
         if (pinned != nullptr) (void)hipHostFree(pinned);
     }
     LevelFeed() = default;
@@ -307,6 +317,7 @@ struct lbl_engine
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
+    int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };
@@ -331,7 +342,7 @@ struct lbl_engine
     template <typename F>
     void timed(int kind, hipStream_t on, F && launch, int counts = 1)
     {
-        if (!timing)
+        if (!timing || (timing == 2 && kind != kTimeAccumulate))
         {
             launch();
             return;
@@ -363,6 +374,20 @@ struct lbl_engine
     {
         for (auto & lane : lanes) lane.drain();
         if (copy_stream != nullptr) (void)hipStreamSynchronize(copy_stream);
+    }
+
+    // Orders `stream` (lane 0's) behind everything queued on the other lanes so far, without
+    // stopping the host: what a call that adds into its output, or reuses lane 0 after calls
+    // that rotated over the lanes, needs.
+    void join_lanes(hipStream_t stream)
+    {
+        for (int i = 1; i < kLanes; ++i)
+        {
+            if (!lanes[i].used) continue;
+            HIP_TRY(hipEventRecord(lanes[i].queued, lanes[i].main));
+            HIP_TRY(hipStreamWaitEvent(stream, lanes[i].queued, 0));
+            lanes[i].used = false;
+        }
     }
 };
 
@@ -453,7 +478,7 @@ int first_row_out_of_range(const Molecule & m, double nu_min, double nu_max)
 
 // Points per lane P (tile = 64*P points) and the tiling.  Cell-aligned tiles are used when
 // they waste at most 6 % of the lanes on padding.
-int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & tiling)
+int pick_tiling(const lbl_engine * engine, int farfield, int n_per_v, long long n, Tiling & tiling)
 {
     const int forced = engine->points_per_lane;
     const bool is_forced = forced == 1 || forced == 2 || forced == 4 || forced == 8;
@@ -479,7 +504,7 @@ int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & ti
     {
         // Measured on the 0.001 cm-1 workload: 4 is ~2 % ahead of 8 for the direct kernel,
         // 8 is ahead when the far-field series carries most lines.
-        p = (n_per_v >= 400 && engine->farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
+        p = (n_per_v >= 400 && farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
     }
     tiling.aligned = 0;
     tiling.per_cell = 0;
@@ -492,7 +517,7 @@ int pick_tiling(const lbl_engine * engine, int n_per_v, long long n, Tiling & ti
 // counts per tile come from the sorted wavenumbers alone (pressure shifts move them by a line
 // or two, which does not matter for balance); the exact per-level cut points are still the
 // schedule kernel's.
-Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
+Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const GridSpec & g,
                           const Tiling & tiling, int points, hipStream_t stream)
 {
     for (size_t i = 0; i < m.plans.size(); ++i)
@@ -500,7 +525,7 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
         Molecule::Plan * p = m.plans[i].get();
         if (p->v0 == g.v0 && p->vn == g.vn && p->n_per_v == g.n_per_v &&
             p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned &&
-            p->farfield == engine->farfield)
+            p->farfield == farfield)
         {
             // Most recently used last.
             std::rotate(m.plans.begin() + i, m.plans.begin() + i + 1, m.plans.end());
@@ -515,7 +540,7 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
     }
     std::unique_ptr<Molecule::Plan> plan(new Molecule::Plan());
     plan->v0 = g.v0; plan->vn = g.vn; plan->n_per_v = g.n_per_v; plan->cut_off = g.cut_off;
-    plan->points = points; plan->aligned = tiling.aligned; plan->farfield = engine->farfield;
+    plan->points = points; plan->aligned = tiling.aligned; plan->farfield = farfield;
     const int n_tiles = tiling.n_tiles;
     const std::vector<double> & nu = m.column[0];
     std::vector<long long> weight((size_t)n_tiles);
@@ -526,7 +551,7 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
         tile_bounds(tiling, t, g.n_per_v, g.n, i0, i1);
         double lo = (double)((i0 + g.n_per_v - 1)/g.n_per_v + g.v0 - g.cut_off - 1) - 0.05;
         double hi = (double)(i1/g.n_per_v + g.v0 + g.cut_off) + 1.05;
-        if (engine->farfield)
+        if (farfield)
         {
             // Only the lines near the tile are evaluated point by point.
             const double u0 = tile_centre(g.v0, g.dv, i0, i1);
@@ -540,7 +565,11 @@ Molecule::Plan & plan_for(lbl_engine * engine, Molecule & m, const GridSpec & g,
     }
     // Aim for ~16 items per workgroup slot of the chip (256 CUs x ~5 resident workgroups),
     // but never items smaller than 512 lines.
-    const long long target = std::max<long long>(engine->farfield ? 128 : 512, total/(16*1280) + 1);
+    // On small grids (a launch does not fill the chip; every scalar load is a miss) short
+    // chains of lines per wavefront matter more than the per-item overhead: 128-line items.
+    const long long floor_lines = engine->item_floor > 0 ? engine->item_floor
+                                  : (n_tiles < 1024 || farfield) ? 128 : 512;
+    const long long target = std::max<long long>(floor_lines, total/(16*1280) + 1);
     std::vector<WorkItem> items;
     std::vector<SplitTile> split;
     std::vector<long long> item_weight;
@@ -648,7 +677,9 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
     }
 
     Tiling tiling;
-    const int points = pick_tiling(engine, rq.n_per_v, n_long, tiling);
+    // The far-field series: an engine-wide option, or this call's choice (LBL_FARFIELD).
+    const int farfield = (engine->farfield || (rq.flags & LBL_FARFIELD)) ? 1 : 0;
+    const int points = pick_tiling(engine, farfield, rq.n_per_v, n_long, tiling);
     const int n_tiles = tiling.n_tiles;
     const int n_cells = rq.vn - rq.v0;
     const bool out_device = (rq.flags & LBL_OUT_DEVICE) != 0;
@@ -662,14 +693,28 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         // output, or that the caller waits for, takes lane 0 with the other lane idle.
         // Only calls with a pedestal gain from sharing the GPU (their serial chain leaves
         // it almost idle); plain calls run back to back on lane 0.
+        // Small grids (a launch does not fill the chip, latency rules) gain the same way.
+        const bool small = n_long*rq.n_levels <= (1ll << 16);
         const bool alternate = (rq.flags & LBL_ASYNC) && !(rq.flags & LBL_ACCUMULATE) &&
-                               want_k && rq.derived == nullptr && rq.remove_pedestal;
+                               want_k && rq.derived == nullptr &&
+                               (rq.remove_pedestal || (small && out_device));
         Lane & lane = engine->lanes[alternate ? (engine->next_lane++ % kLanes) : 0];
+        hipStream_t stream = lane.main;
         if (!alternate)
         {
-            for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+            if ((rq.flags & LBL_ASYNC) && out_device)
+            {
+                engine->join_lanes(stream);     // the host keeps queueing
+            }
+            else
+            {
+                for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+            }
         }
-        hipStream_t stream = lane.main;
+        else
+        {
+            lane.used = true;
+        }
         if (alternate && out_device)
         {
             // Calls on different lanes run side by side; two that write the same memory must
@@ -686,7 +731,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
         }
 
-        Molecule::Plan & plan = plan_for(engine, *m, g, tiling, points, stream);
+        Molecule::Plan & plan = plan_for(engine, farfield, *m, g, tiling, points, stream);
 
         // Levels per pass, bounded by the workspace budget.
         const long long per_level = plan.partial_slots*64*points*8 + n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
@@ -712,7 +757,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         lane.schedule.reserve((size_t)(chunk*n_tiles));
         if (want_k && !out_device) lane.staging.reserve((size_t)(chunk*n_long));
         if (with_pedestal && out_device && add_into) lane.raw.reserve((size_t)(chunk*n_long));
-        if (want_k && engine->farfield) lane.far_series.reserve((size_t)(chunk*n_tiles*kFarTerms));
+        if (want_k && farfield) lane.far_series.reserve((size_t)(chunk*n_tiles*kFarTerms));
         if (want_k) lane.partial.reserve((size_t)std::max(1ll, chunk*plan.partial_slots*64*points));
         if (rq.evals != nullptr)
         {
@@ -740,53 +785,82 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                                 "level " + std::to_string(base + l) + ": " + why);
                 }
             }
-            HIP_TRY(hipMemcpyAsync(lane.levels.data, lane.pinned_levels,
-                                   count*sizeof(LevelScalars), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipEventRecord(lane.levels_copied, stream));
-            lane.levels_in_flight = true;
-
-            // K1: per-line scalars.
-            if (n_lines > 0 && engine->prep == LBL_PREP_HOST)
+            // A few levels travel as kernel arguments of the prologue kernel (no copy in front
+            // of it); more go through the pinned block.
+            const bool host_prep = engine->prep == LBL_PREP_HOST;
+            const bool inline_levels = !host_prep && count <= kInlineLevels;
+            if (!inline_levels)
             {
-                host_wing.resize((size_t)(count*n_lines));
-                host_core.resize((size_t)(count*n_lines));
-                if (rq.derived != nullptr) host_derived.assign((size_t)(n_lines*8), 0.);
-                unsigned long long total = 0;
-                for (int l = 0; l < count; ++l)
-                {
-                    for (long long j = 0; j < n_lines; ++j)
-                    {
-                        const bool ok = m->iso_slot[j] >= 0 &&
-                                        line_accepted(rule, m->column[0][j], m->order[j]);
-                        double * d = (rq.derived != nullptr && l == 0)
-                                     ? host_derived.data() + j*8 : nullptr;
-                        LineWing & w = host_wing[(size_t)(l*n_lines + j)];
-                        const int status = prepare_line(
-                            lane.pinned_levels[l], g, m->column[0][j], m->column[1][j],
-                            m->column[2][j], m->column[3][j], m->column[4][j], m->column[5][j],
-                            m->column[6][j], std::max(m->iso_slot[j], 0), ok, w,
-                            host_core[(size_t)(l*n_lines + j)], d);
-                        if (status == 1 && w.last >= w.first) total += w.last - w.first + 1;
-                    }
-                }
-                engine->timed(kTimePrepare, stream, [&] {
-                    HIP_TRY(hipMemcpyAsync(lane.wing.data, host_wing.data(),
-                                           host_wing.size()*sizeof(LineWing),
-                                           hipMemcpyHostToDevice, stream));
-                    HIP_TRY(hipMemcpyAsync(lane.core.data, host_core.data(),
-                                           host_core.size()*sizeof(LineCore),
-                                           hipMemcpyHostToDevice, stream));
-                });
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (rq.evals != nullptr) *rq.evals += (int64_t)total;
+                HIP_TRY(hipMemcpyAsync(lane.levels.data, lane.pinned_levels,
+                                       count*sizeof(LevelScalars), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipEventRecord(lane.levels_copied, stream));
+                lane.levels_in_flight = true;
             }
-            else if (n_lines > 0)
+
+            // K1: per-line scalars (+ the tile cut points, in the same launch).
+            if (host_prep)
             {
+                if (n_lines > 0)
+                {
+                    host_wing.resize((size_t)(count*n_lines));
+                    host_core.resize((size_t)(count*n_lines));
+                    if (rq.derived != nullptr) host_derived.assign((size_t)(n_lines*8), 0.);
+                    unsigned long long total = 0;
+                    for (int l = 0; l < count; ++l)
+                    {
+                        for (long long j = 0; j < n_lines; ++j)
+                        {
+                            const bool ok = m->iso_slot[j] >= 0 &&
+                                            line_accepted(rule, m->column[0][j], m->order[j]);
+                            double * d = (rq.derived != nullptr && l == 0)
+                                         ? host_derived.data() + j*8 : nullptr;
+                            LineWing & w = host_wing[(size_t)(l*n_lines + j)];
+                            const int status = prepare_line(
+                                lane.pinned_levels[l], g, m->column[0][j], m->column[1][j],
+                                m->column[2][j], m->column[3][j], m->column[4][j], m->column[5][j],
+                                m->column[6][j], std::max(m->iso_slot[j], 0), ok, w,
+                                host_core[(size_t)(l*n_lines + j)], d);
+                            if (status == 1 && w.last >= w.first) total += w.last - w.first + 1;
+                        }
+                    }
+                    engine->timed(kTimePrepare, stream, [&] {
+                        HIP_TRY(hipMemcpyAsync(lane.wing.data, host_wing.data(),
+                                               host_wing.size()*sizeof(LineWing),
+                                               hipMemcpyHostToDevice, stream));
+                        HIP_TRY(hipMemcpyAsync(lane.core.data, host_core.data(),
+                                               host_core.size()*sizeof(LineCore),
+                                               hipMemcpyHostToDevice, stream));
+                    });
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (rq.evals != nullptr) *rq.evals += (int64_t)total;
+                }
+                if (want_k)
+                {
+                    engine->timed(kTimeSchedule, stream, [&] {
+                        dim3 grid((unsigned)((8ll*n_tiles + 255)/256), (unsigned)count);
+                        hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, stream,
+                                           m->d_column[0].data, (int)n_lines, lane.levels.data, g,
+                                           tiling, farfield, lane.schedule.data);
+                        HIP_TRY(hipGetLastError());
+                    });
+                }
+            }
+            else
+            {
+                InlineLevels packed;
+                if (inline_levels)
+                {
+                    std::memcpy(packed.level, lane.pinned_levels, count*sizeof(LevelScalars));
+                }
+                const int prepare_blocks = (int)((n_lines + 255)/256);
+                const int schedule_blocks = want_k ? (int)((8ll*n_tiles + 255)/256) : 0;
                 engine->timed(kTimePrepare, stream, [&] {
-                    dim3 grid((unsigned)((n_lines + 255)/256), (unsigned)count);
-                    hipLaunchKernelGGL(prepare_kernel, grid, dim3(256), 0, stream, m->view(),
-                                       lane.levels.data, g, rule, lane.wing.data,
-                                       lane.core.data,
+                    dim3 grid((unsigned)std::max(prepare_blocks + schedule_blocks, 1),
+                              (unsigned)count);
+                    hipLaunchKernelGGL(prologue_kernel, grid, dim3(256), 0, stream, m->view(),
+                                       lane.levels.data, packed, inline_levels ? 1 : 0, g, rule,
+                                       tiling, farfield, prepare_blocks, lane.wing.data,
+                                       lane.core.data, lane.schedule.data,
                                        rq.derived != nullptr ? lane.derived.data : nullptr,
                                        rq.evals != nullptr ? lane.evals.data : nullptr);
                     HIP_TRY(hipGetLastError());
@@ -797,8 +871,8 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
 
             // The pedestal pre-pass only needs the per-line scalars: it runs on the side
             // stream next to the accumulate kernel (its serial chain keeps one CU busy).
-            // Its run-finding kernels go first, beside schedule_kernel: once the accumulate
-            // grid owns the chip their wide workgroups would wait for it to drain.
+            // Its run-finding kernels go first: once the accumulate grid owns the chip their
+            // wide workgroups would wait for it to drain.
             hipStream_t ped_stream = engine->overlap_pedestal ? lane.side : stream;
             if (with_pedestal)
             {
@@ -817,15 +891,6 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 }
             }
 
-            // Tile cut points.
-            engine->timed(kTimeSchedule, stream, [&] {
-                dim3 grid((unsigned)((n_tiles + 255)/256), (unsigned)count);
-                hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, stream,
-                                   m->d_column[0].data, (int)n_lines, lane.levels.data, g,
-                                   tiling, engine->farfield, lane.schedule.data);
-                HIP_TRY(hipGetLastError());
-            });
-
             // Where the spectra of this pass end up, and where the accumulate kernel writes.
             double * target = out_device ? rq.k + base*stride : lane.staging.data;
             const long long target_stride = out_device ? stride : n_long;
@@ -843,7 +908,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.schedule = lane.schedule.data;
             args.levels = lane.levels.data;
             args.items = plan.items.data;
-            args.far_series = engine->farfield ? lane.far_series.data : nullptr;
+            args.far_series = farfield ? lane.far_series.data : nullptr;
             args.partial = lane.partial.data;
             args.partial_slots = plan.partial_slots;
             args.level_stride = sums_stride;
@@ -865,7 +930,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                 HIP_TRY(hipStreamWaitEvent(stream, lane.runs_found, 0));
             }
             engine->timed(kTimeAccumulate, stream, [&] {
-                if (engine->farfield)
+                if (farfield)
                 {
                     dim3 far_grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
                     hipLaunchKernelGGL(farfield_kernel, far_grid, dim3(256), 0, stream,
@@ -1222,7 +1287,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->points_per_lane = (int)value;
     }
-    else if (key == "timing" && (value == 0 || value == 1))
+    else if (key == "timing" && value >= 0 && value <= 2)
     {
         engine->timing = (int)value;
     }
@@ -1233,6 +1298,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "scan_chain" && (value == 0 || value == 1))
     {
         engine->scan_chain = (int)value;
+    }
+    else if (key == "item_floor" && value >= 0 && value <= 65536)
+    {
+        engine->item_floor = (int)value;
     }
     else if (key == "farfield" && (value == 0 || value == 1))
     {

@@ -42,17 +42,148 @@ __host__ __device__ inline bool line_accepted(const RangeRule & r, double nu, in
     return !(nu > r.nu_max || nu < r.nu_min);
 }
 
-// One thread per (line, level).
-__global__ __launch_bounds__(256) void prepare_kernel(const LineTableView t,
-                                                      const LevelScalars * __restrict__ levels,
-                                                      const GridSpec g, const RangeRule rule,
-                                                      LineWing * __restrict__ wing,
-                                                      LineCore * __restrict__ core,
-                                                      double * __restrict__ derived,
-                                                      unsigned long long * __restrict__ evals)
+__device__ inline int first_not_below(const double * __restrict__ nu, int n, double x)
 {
-    const long long j = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+    int lo = 0, hi = n;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (nu[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline int first_above(const double * __restrict__ nu, int n, double x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (nu[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Eight threads per (tile, level), one binary search each (the searches are chains of
+// dependent loads: side by side they take the time of one).  A line's window is fixed by
+// b = floor(nu + p*delta): [b-cut, b+cut+1] cm-1, both ends included (spectra.c:48-62).  With
+// |p*delta| <= shift_max the tests on b become tests on nu, which is the sort key:
+//   may overlap the tile    b in [ceil(i0/npv)+v0-cut-1, floor(i1/npv)+v0+cut]
+//   covers the whole tile   b in [ceil(i1/npv)+v0-cut-1, floor(i0/npv)+v0+cut]
+//   tile may touch |x|<xlim0    |nu - tile| <= core_reach*nu (+ shift)
+__device__ __forceinline__ void schedule_tile(const double * __restrict__ nu, int n_lines,
+                                              const LevelScalars & lv, const GridSpec & g,
+                                              const Tiling & tiling, const int farfield,
+                                              int tile, int which, bool active,
+                                              TileSchedule * __restrict__ out)
+{
+    long long i0 = 0, i1 = 0;
+    if (active) tile_bounds(tiling, tile, g.n_per_v, g.n, i0, i1);
+    const double smax = lv.shift_max;
+    const long long npv = g.n_per_v;
+    const double any_lo = (double)((i0 + npv - 1)/npv + g.v0 - g.cut_off - 1);
+    const double any_hi = (double)(i1/npv + g.v0 + g.cut_off);
+    const double full_lo = (double)((i1 + npv - 1)/npv + g.v0 - g.cut_off - 1);
+    const double full_hi = (double)(i0/npv + g.v0 + g.cut_off);
+    const double v_lo = (double)g.v0 + (double)i0*g.dv;
+    const double v_hi = (double)g.v0 + (double)i1*g.dv;
+    const double kk = lv.core_reach;
+    const bool bounded = kk < 0.5;
+    const double core = bounded ? kk*(v_hi + smax)/(1. - kk)*(1. + 1.e-9) + smax + 1.e-9 : 0.;
+    const double half = 0.5*(v_hi - v_lo);
+    const double u0 = tile_centre(g.v0, g.dv, i0, i1);
+    const double radius = fmax(kFarRatio*half, core + half)*(1. + 1.e-9) + 1.e-6;
+    // which: 0 lo, 1 a1, 2 c1, 3 c2, 4 a2, 5 hi, 6 f1, 7 f2 (the order of TileSchedule).
+    double key;
+    bool above = false;         // first index with nu > key (else: nu >= key)
+    switch (which)
+    {
+    case 0: key = any_lo - smax; break;
+    case 1: key = full_lo + smax; break;
+    case 2: key = v_lo - core; break;
+    case 3: key = v_hi + core; above = true; break;
+    case 4: key = full_hi + 1. - smax; break;
+    case 5: key = any_hi + 1. + smax; break;
+    case 6: key = u0 - radius - smax; above = true; break;
+    default: key = u0 + radius + smax; break;
+    }
+    int found = 0;
+    if (active)
+    {
+        found = above ? first_above(nu, n_lines, key) : first_not_below(nu, n_lines, key);
+    }
+    const int lane = threadIdx.x & 63;
+    const int leader = lane & ~7;
+    int value[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+    {
+        value[k] = __shfl(found, leader + k, 64);
+    }
+    if (which != 0 || !active)
+    {
+        return;
+    }
+    TileSchedule s;
+    s.lo = value[0]; s.a1 = value[1]; s.c1 = value[2]; s.c2 = value[3];
+    s.a2 = value[4]; s.hi = value[5];
+    if (!bounded)
+    {
+        s.c1 = 0;
+        s.c2 = n_lines;
+    }
+    if (s.hi < s.lo) s.hi = s.lo;
+    s.a1 = min(max(s.a1, s.lo), s.hi);
+    s.a2 = min(max(s.a2, s.a1), s.hi);
+    s.c1 = min(max(s.c1, s.a1), s.a2);
+    s.c2 = min(max(s.c2, s.c1), s.a2);
+    // Far-field split (farfield.h): lines at least kFarRatio half-widths from the tile
+    // centre, and beyond every possible core, go to the series; without it the ranges
+    // [a1,f1) and [f2,a2) are empty.
+    s.f1 = s.a1;
+    s.f2 = s.a2;
+    if (farfield && bounded)
+    {
+        s.f1 = min(max(value[6], s.a1), s.c1);
+        s.f2 = min(max(value[7], s.c2), s.a2);
+    }
+    *out = s;
+}
+
+__global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict__ nu, int n_lines,
+                                                       const LevelScalars * __restrict__ levels,
+                                                       const GridSpec g, const Tiling tiling,
+                                                       const int farfield,
+                                                       TileSchedule * __restrict__ schedule)
+{
+    const int thread = blockIdx.x*blockDim.x + threadIdx.x;
+    const int tile = thread >> 3;
     const int level = blockIdx.y;
+    const bool active = tile < tiling.n_tiles;
+    schedule_tile(nu, n_lines, levels[level], g, tiling, farfield, tile, thread & 7, active,
+                  schedule + (long long)level*tiling.n_tiles + (active ? tile : 0));
+}
+
+// prepare_kernel and schedule_kernel in one launch (they are independent: the schedule only
+// reads the sorted wavenumbers and the level scalars): blocks [0, prepare_blocks) prepare
+// lines, the rest schedule tiles.  For a few levels the level scalars travel as kernel
+// arguments (no host-to-device copy in front of the launch) and block 0 of each level stores
+// them where the later kernels read them.
+constexpr int kInlineLevels = 4;
+struct InlineLevels
+{
+    LevelScalars level[kInlineLevels];
+};
+
+__device__ __forceinline__ void prepare_block(const LineTableView & t, const LevelScalars & lv,
+                                              const GridSpec & g, const RangeRule & rule,
+                                              int block, int level,
+                                              LineWing * __restrict__ wing,
+                                              LineCore * __restrict__ core,
+                                              double * __restrict__ derived,
+                                              unsigned long long * __restrict__ evals)
+{
+    const long long j = (long long)block*blockDim.x + threadIdx.x;
     unsigned long long count = 0;
     if (j < t.n_lines)
     {
@@ -62,7 +193,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(const LineTableView t,
         const int slot = t.iso_slot[j];     // -1: no mass / partition function (never accepted)
         const bool ok = slot >= 0 && line_accepted(rule, nu, t.row[j]);
         double * d = derived != nullptr ? derived + ((long long)level*t.n_lines + j)*8 : nullptr;
-        const int status = prepare_line(levels[level], g, nu, t.sw[j], t.gamma_air[j],
+        const int status = prepare_line(lv, g, nu, t.sw[j], t.gamma_air[j],
                                         t.gamma_self[j], t.n_air[j], t.elower[j],
                                         t.delta_air[j], max(slot, 0), ok, w, c, d);
         wing[(long long)level*t.n_lines + j] = w;
@@ -86,101 +217,38 @@ __global__ __launch_bounds__(256) void prepare_kernel(const LineTableView t,
     }
 }
 
-__device__ inline int first_not_below(const double * __restrict__ nu, int n, double x)
+__global__ __launch_bounds__(256) void prologue_kernel(const LineTableView t,
+                                                       LevelScalars * __restrict__ levels,
+                                                       const InlineLevels inline_levels,
+                                                       const int use_inline,
+                                                       const GridSpec g, const RangeRule rule,
+                                                       const Tiling tiling, const int farfield,
+                                                       const int prepare_blocks,
+                                                       LineWing * __restrict__ wing,
+                                                       LineCore * __restrict__ core,
+                                                       TileSchedule * __restrict__ schedule,
+                                                       double * __restrict__ derived,
+                                                       unsigned long long * __restrict__ evals)
 {
-    int lo = 0, hi = n;
-    while (lo < hi)
-    {
-        const int mid = (lo + hi) >> 1;
-        if (nu[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ inline int first_above(const double * __restrict__ nu, int n, double x)
-{
-    int lo = 0, hi = n;
-    while (lo < hi)
-    {
-        const int mid = (lo + hi) >> 1;
-        if (nu[mid] <= x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// One thread per (tile, level).  A line's window is fixed by b = floor(nu + p*delta):
-// [b-cut, b+cut+1] cm-1, both ends included (spectra.c:48-62).  With |p*delta| <= shift_max
-// the tests on b become tests on nu, which is the sort key:
-//   may overlap the tile    b in [ceil(i0/npv)+v0-cut-1, floor(i1/npv)+v0+cut]
-//   covers the whole tile   b in [ceil(i1/npv)+v0-cut-1, floor(i0/npv)+v0+cut]
-//   tile may touch |x|<xlim0    |nu - tile| <= core_reach*nu (+ shift)
-__global__ __launch_bounds__(256) void schedule_kernel(const double * __restrict__ nu, int n_lines,
-                                                       const LevelScalars * __restrict__ levels,
-                                                       const GridSpec g, const Tiling tiling,
-                                                       const int farfield,
-                                                       TileSchedule * __restrict__ schedule)
-{
-    const int tile = blockIdx.x*blockDim.x + threadIdx.x;
     const int level = blockIdx.y;
-    const int n_tiles = tiling.n_tiles;
-    if (tile >= n_tiles)
+    const LevelScalars & lv = use_inline ? inline_levels.level[level] : levels[level];
+    if (use_inline && blockIdx.x == 0)
     {
+        // sizeof(LevelScalars) is a multiple of 8: copy as doubles, one per thread.
+        const double * from = reinterpret_cast<const double *>(&inline_levels.level[level]);
+        double * to = reinterpret_cast<double *>(levels + level);
+        for (int i = threadIdx.x; i < (int)(sizeof(LevelScalars)/8); i += blockDim.x) to[i] = from[i];
+    }
+    if ((int)blockIdx.x < prepare_blocks)
+    {
+        prepare_block(t, lv, g, rule, blockIdx.x, level, wing, core, derived, evals);
         return;
     }
-    long long i0, i1;
-    tile_bounds(tiling, tile, g.n_per_v, g.n, i0, i1);
-    const double smax = levels[level].shift_max;
-    const long long npv = g.n_per_v;
-    const double any_lo = (double)((i0 + npv - 1)/npv + g.v0 - g.cut_off - 1);
-    const double any_hi = (double)(i1/npv + g.v0 + g.cut_off);
-    const double full_lo = (double)((i1 + npv - 1)/npv + g.v0 - g.cut_off - 1);
-    const double full_hi = (double)(i0/npv + g.v0 + g.cut_off);
-    TileSchedule s;
-    s.lo = first_not_below(nu, n_lines, any_lo - smax);
-    s.hi = first_not_below(nu, n_lines, any_hi + 1. + smax);
-    s.a1 = first_not_below(nu, n_lines, full_lo + smax);
-    s.a2 = first_not_below(nu, n_lines, full_hi + 1. - smax);
-    const double v_lo = (double)g.v0 + (double)i0*g.dv;
-    const double v_hi = (double)g.v0 + (double)i1*g.dv;
-    const double kk = levels[level].core_reach;
-    if (kk < 0.5)
-    {
-        const double reach = kk*(v_hi + smax)/(1. - kk)*(1. + 1.e-9) + smax + 1.e-9;
-        s.c1 = first_not_below(nu, n_lines, v_lo - reach);
-        s.c2 = first_above(nu, n_lines, v_hi + reach);
-    }
-    else
-    {
-        s.c1 = 0;
-        s.c2 = n_lines;
-    }
-    if (s.hi < s.lo) s.hi = s.lo;
-    s.a1 = min(max(s.a1, s.lo), s.hi);
-    s.a2 = min(max(s.a2, s.a1), s.hi);
-    // Normally every line that may have its core in the tile also covers it completely
-    // (cores reach ~1 cm-1, windows 25); with a tiny cut-off the clipping ranges can hold such
-    // lines too, and the accumulate kernel then takes them through its core path.
-    s.clip_core = (s.c1 < s.a1 && s.a1 > s.lo) || (s.c2 > s.a2 && s.a2 < s.hi) ? 1 : 0;
-    s.pad[0] = s.pad[1] = s.pad[2] = 0;
-    s.c1 = min(max(s.c1, s.a1), s.a2);
-    s.c2 = min(max(s.c2, s.c1), s.a2);
-    // Far-field split (farfield.h): lines at least kFarRatio half-widths from the tile
-    // centre, and beyond every possible core, go to the series; without it the ranges
-    // [a1,f1) and [f2,a2) are empty.
-    s.f1 = s.a1;
-    s.f2 = s.a2;
-    if (farfield && kk < 0.5)
-    {
-        const double half = 0.5*(v_hi - v_lo);
-        const double u0 = tile_centre(g.v0, g.dv, i0, i1);
-        const double core = kk*(v_hi + smax)/(1. - kk)*(1. + 1.e-9) + smax + 1.e-9;
-        const double radius = fmax(kFarRatio*half, core + half)*(1. + 1.e-9) + 1.e-6;
-        s.f1 = first_above(nu, n_lines, u0 - radius - smax);
-        s.f2 = first_not_below(nu, n_lines, u0 + radius + smax);
-        s.f1 = min(max(s.f1, s.a1), s.c1);
-        s.f2 = min(max(s.f2, s.c2), s.a2);
-    }
-    schedule[(long long)level*n_tiles + tile] = s;
+    const int thread = (blockIdx.x - prepare_blocks)*blockDim.x + threadIdx.x;
+    const int tile = thread >> 3;
+    const bool active = tile < tiling.n_tiles;
+    schedule_tile(t.nu, (int)t.n_lines, lv, g, tiling, farfield, tile, thread & 7, active,
+                  schedule + (long long)level*tiling.n_tiles + (active ? tile : 0));
 }
 
 }  // namespace lbl

@@ -19,7 +19,7 @@ LIBRARY_PATH = Path(__file__).resolve().parent / "liblbl_amd.so"
 LBL_OK = 0
 RANGE_REFERENCE, RANGE_SKIP = 0, 1
 PREP_DEVICE, PREP_HOST = 0, 1
-OUT_DEVICE, ASYNC, SCALE_DENSITY, ACCUMULATE = 1, 2, 4, 8
+OUT_DEVICE, ASYNC, SCALE_DENSITY, ACCUMULATE, FARFIELD = 1, 2, 4, 8, 16
 RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
 
 EXPORTED_SYMBOLS = (
@@ -190,6 +190,38 @@ class DeviceSpectra(object):
             pass
 
 
+class DevicePool(object):
+    """[levels, n] blocks in HBM handed out and taken back (hipMalloc / hipFree cost more than
+    the continuum kernels that fill such a block, and hipFree stops the device)."""
+    def __init__(self, engine, limit=32 << 30):
+        self.engine = weakref.ref(engine)
+        self.limit = limit
+        self.idle = {}          # shape -> [DeviceSpectra]
+        self.idle_bytes = 0
+
+    def take(self, levels, n):
+        shape = (int(levels), int(n))
+        blocks = self.idle.get(shape)
+        if blocks:
+            self.idle_bytes -= shape[0]*shape[1]*8
+            return blocks.pop()
+        return DeviceSpectra(self.engine(), *shape)
+
+    def give(self, block):
+        size = block.shape[0]*block.shape[1]*8
+        if not block.pointer or self.idle_bytes + size > self.limit:
+            block.free()
+            return
+        self.idle.setdefault(tuple(block.shape), []).append(block)
+        self.idle_bytes += size
+
+    def clear(self):
+        for blocks in self.idle.values():
+            for block in blocks:
+                block.free()
+        self.idle, self.idle_bytes = {}, 0
+
+
 class PinnedPool(object):
     """Page-locked host arrays for results.  Pinning memory is slow, so buffers are recycled:
     when the last view of an array handed out here is garbage-collected its buffer goes back
@@ -258,6 +290,7 @@ class Engine(object):
             raise EngineError(f"lbl_engine_create failed ({status}): {message}")
         self.device = int(device)
         self.pinned = PinnedPool(self)
+        self.blocks = DevicePool(self)
 
     def host_array(self, shape):
         """float64 array of the given shape in page-locked host memory (recycled, see
@@ -271,6 +304,7 @@ class Engine(object):
     def close(self):
         if self.handle:
             self.pinned.clear()
+            self.blocks.clear()
             self.lib.lbl_engine_destroy(self.handle)
             self.handle = c_void_p()
 
@@ -305,7 +339,7 @@ class Engine(object):
 
     def compute(self, molecule, temperature, pressure, vmr, v0, vn, n_per_v, cut_off=25,
                 remove_pedestal=False, range_policy="reference", out=None, scale_density=False,
-                accumulate=False, asynchronous=False, want_evals=False):
+                accumulate=False, asynchronous=False, want_evals=False, farfield=False):
         """Cross sections [m2] for every level: returns float64[levels, (vn-v0)*n_per_v]
         (or fills `out`: a host array or a DeviceSpectra)."""
         t, p, x = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure)), \
@@ -314,7 +348,7 @@ class Engine(object):
             raise ValueError("temperature, pressure and vmr must be 1-d and equally long.")
         n = (int(vn) - int(v0))*int(n_per_v)
         flags = (SCALE_DENSITY if scale_density else 0) | (ACCUMULATE if accumulate else 0) | \
-                (ASYNC if asynchronous else 0)
+                (ASYNC if asynchronous else 0) | (FARFIELD if farfield else 0)
         if hasattr(out, "pointer"):
             # Device memory: a DeviceSpectra or anything exposing .pointer and .shape.
             if tuple(out.shape) != (t.size, n):

@@ -85,8 +85,12 @@ class Gas(object):
     def absorption_coefficients(self, temperature, pressure, volume_mixing_ratio, grid,
                                 remove_pedestal=False, cut_off=25, range_policy="reference",
                                 out=None, scale_density=False, accumulate=False,
-                                asynchronous=False):
-        """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v]."""
+                                asynchronous=False, farfield=False):
+        """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v].
+
+        farfield: sum the lines far from each tile of the grid through one power series per tile
+        (engine flag LBL_FARFIELD; truncation <= ~1.5e-11 relative, several times faster on fine
+        grids)."""
         if self._deferred_error is not None:
             raise self._deferred_error
         v0, vn, n_per_v = grid_arguments(grid)
@@ -111,7 +115,7 @@ class Gas(object):
                                    v0, vn, n_per_v, cut_off=cut_off,
                                    remove_pedestal=remove_pedestal, range_policy=range_policy,
                                    out=out, scale_density=scale_density, accumulate=accumulate,
-                                   asynchronous=asynchronous)
+                                   asynchronous=asynchronous, farfield=farfield)
 
     def __del__(self):
         try:

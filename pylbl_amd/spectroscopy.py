@@ -116,7 +116,7 @@ class _Sum(object):
     """A [levels, n] block in HBM that kernels write first and add into afterwards."""
     def __init__(self, engine, levels, n):
         self.engine = engine
-        self.buffer = DeviceSpectra(engine, levels, n)
+        self.buffer = engine.blocks.take(levels, n)     # recycled (engine.DevicePool)
         self.written = False
 
     def take(self):
@@ -140,9 +140,14 @@ class Spectroscopy(object):
     """
     def __init__(self, atmosphere, grid, database, mapping=None, lines_backend="mi355x",
                  continua_backend="mt_ckd", cross_sections_backend="arts_crossfit", device=0,
-                 group=None, gather_to=0):
+                 group=None, gather_to=0, farfield=True):
         """Args beyond the reference's (pyLBL/spectroscopy.py:88-118):
             device: GPU index of this process.
+            farfield: True (default): lines far from a tile of the grid enter through one power
+                   series per tile (pylbl_amd/csrc/farfield.h; truncation <= ~1.5e-11 relative,
+                   asserted by tests/test_gpu_api.py at 100, 1000 and 2000 points per cm-1;
+                   3-4x faster on fine grids).  False: every line at every point of its window,
+                   like the reference's loop.
             group: None: this process computes every level.  True (the default process group)
                    or a torch.distributed ProcessGroup: one process per GPU, each computes a
                    contiguous block of levels (all gases and mechanisms of a level on the same
@@ -167,6 +172,7 @@ class Spectroscopy(object):
         self.device = device
         self.group = group
         self.gather_to = gather_to
+        self.farfield = bool(farfield)
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
@@ -277,7 +283,7 @@ class Spectroscopy(object):
                     blocks[(name, 0)] = gas.absorption_coefficients(
                         temperature, pressure, mole_fractions[name], self.grid,
                         remove_pedestal=remove_pedestal, range_policy=range_policy,
-                        scale_density=True)[:, :columns]
+                        scale_density=True, farfield=self.farfield)[:, :columns]
                 for continuum in continua_here:
                     values = continuum.spectra_levels(temperature, pressure, mole_fractions,
                                                       self.grid)
@@ -303,7 +309,7 @@ class Spectroscopy(object):
                     temperature, pressure, mole_fractions[name], self.grid,
                     remove_pedestal=remove_pedestal, range_policy=range_policy,
                     scale_density=True, out=lines_sum.buffer, accumulate=lines_sum.take(),
-                    asynchronous=True)
+                    asynchronous=True, farfield=self.farfield)
             for continuum in continua_here:
                 continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
                                          out=continuum_sum.buffer,
@@ -332,7 +338,7 @@ class Spectroscopy(object):
         if engine is not None:
             engine.synchronize()
         for block in in_flight:
-            block.buffer.free()
+            engine.blocks.give(block.buffer)
 
         if mode == "total":
             values = results.get("total")

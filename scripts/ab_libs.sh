@@ -1,13 +1,17 @@
 #!/bin/bash
-# A/B of prebuilt engine libraries (build/liblbl_<name>.so) on the default bench, interleaved.
+# A/B of prebuilt engine libraries (build/liblbl_<name>.so, same C ABI as the working tree) on
+# several workloads, interleaved; prints the event-timed accumulate time per step.
+# Usage on the GPU box: scripts/ab_libs.sh <name> <name> ...   (ROUNDS=2 by default)
 cp pylbl_amd/liblbl_amd.so /tmp/orig.so
-for round in 1 2 3; do
+for round in $(seq 1 ${ROUNDS:-2}); do
+for args in "" "--config 1" "--levels-per-gpu 8 --profile standard" "--farfield"; do
 for name in "$@"; do
   cp build/liblbl_$name.so pylbl_amd/liblbl_amd.so
-  python bench.py --steps 10 --warmup 3 --no-extras $BENCH_ARGS 2>/dev/null | python -c "
+  python bench.py --steps 20 --warmup 3 --no-extras $args 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('$name round $round', 'evals/s %.4g' % d['value'], 'ms/step %.3f' % d['ms_per_step'], 'acc/launch %.3f' % d['roofline']['avg_launch_ms'])"
+print('%-8s round $round %-42s ms/step %.4f accumulate ms/step %.4f' % ('$name', '$args', d['ms_per_step'], d['kernel_ms_per_step']['accumulate']))"
+done
 done
 done
 cp /tmp/orig.so pylbl_amd/liblbl_amd.so

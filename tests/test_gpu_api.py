@@ -588,3 +588,26 @@ def test_grid_edited_in_place_is_uploaded_again(continuum_oracle):
     expect = continuum_oracle.continuum("CO2").spectra(288.99, 98388., vmr, grid)
     np.testing.assert_allclose(second, expect, rtol=1e-6, atol=1e-300)
     assert not np.array_equal(first, second)
+
+
+@pytest.mark.parametrize("npv,span", [(100, 400), (1000, 60), (2000, 40)])
+def test_farfield_truncation_bound_per_resolution(oracle, npv, span):
+    """Spectroscopy sums distant lines through the far-field series by default (per-call flag
+    LBL_FARFIELD).  Its design bound -- |u|/|a| <= 1/4, 21 terms: truncation <= ~1.5e-11
+    relative -- is asserted here against the direct kernel at the resolutions of BASELINE
+    configs[1], the target and configs[4], at 1 atm and 10 Pa, and the result meets the 1e-6 bar
+    against the oracle."""
+    from pylbl_amd.engine import Engine
+    e = Engine(0)
+    v0 = 2000
+    vn = v0 + span
+    table = synthetic.line_table("CO2", v0 - 25., vn + 25., num_lines=80*(span + 50), seed=17)
+    h = e.load(table)
+    for t, p in ((288.99, 98388.), (232.7, 10.)):
+        direct = e.compute(h, t, p, 3.6e-4, v0, vn, npv)[0]
+        series = e.compute(h, t, p, 3.6e-4, v0, vn, npv, farfield=True)[0]
+        assert not np.array_equal(series, direct)           # the flag does change the path
+        assert np.max(np.abs(series - direct)/direct) < 1.e-10, (npv, p)
+    k_ref, _ = oracle.absorption_port(table, 232.7, 10., 3.6e-4, v0, vn, npv)
+    np.testing.assert_allclose(series, k_ref, rtol=1.e-6)
+    e.close()
