@@ -288,7 +288,8 @@ def profiled_issue(workload):
                     return {"fp64_wave_instructions_per_launch": fp64,
                             "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
                             "evals_per_launch": summary.get("evals_per_accumulate_launch"),
-                            "gui_active_cycles_per_launch": c.get("GRBM_GUI_ACTIVE"),
+                            "gui_active_cycles_per_xcd": entry.get("gui_active_cycles_per_xcd"),
+                            "sclk_ghz_measured": entry.get("sclk_ghz_from_gui_active"),
                             "source": f"profiles/{os.path.basename(path)}"}
         except (OSError, KeyError, TypeError, ValueError):
             continue
@@ -744,10 +745,13 @@ def main():
                 "fp64_wave_instructions_per_64_evals": per_eval,
                 "issue_ceiling_evals_per_s_at_2.4GHz": ceiling,
                 "frac_of_issue_ceiling_at_2.4GHz": evals_per_launch/(accumulate_ms*1e-3)/ceiling})
-            if issue.get("gui_active_cycles_per_launch"):
-                cycles = issue["gui_active_cycles_per_launch"]
+            if issue.get("gui_active_cycles_per_xcd"):
+                # Busy cycles of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs): the fraction of
+                # a SIMD's 4-cycle issue slots that fp64 instructions occupied at the clock the
+                # chip actually ran.
                 per_simd = issue["fp64_wave_instructions_per_launch"]/SIMDS*4.
-                issue["frac_of_issue_slots_at_measured_clock"] = per_simd/cycles
+                issue["frac_of_issue_slots_at_measured_clock"] = \
+                    per_simd/issue["gui_active_cycles_per_xcd"]
             line["roofline"]["issue"] = issue
         if args.pedestal:
             line["roofline"]["note"] += ("; remove_pedestal=True: calls alternate between engine "

@@ -13,7 +13,8 @@ i=0
 for group in "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" \
              "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"; do
+             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+             "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   rocprofv3 --pmc $group --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-extras "$@" > $OUT/bench$i.json 2> $OUT/pass$i.err || exit 1
 done

@@ -611,3 +611,35 @@ def test_farfield_truncation_bound_per_resolution(oracle, npv, span):
     k_ref, _ = oracle.absorption_port(table, 232.7, 10., 3.6e-4, v0, vn, npv)
     np.testing.assert_allclose(series, k_ref, rtol=1.e-6)
     e.close()
+
+
+def test_spectroscopy_farfield_flag_and_block_pool(small_database):
+    """Spectroscopy(farfield=True), the default, differs from farfield=False only at the series'
+    truncation level; the [levels, n] blocks in HBM are recycled between calls."""
+    from pylbl_amd import MemoryDatabase, Spectroscopy
+    tables = [synthetic.line_table("H2O", 580., 700., num_lines=4000, seed=5),
+              synthetic.line_table("CO2", 580., 700., num_lines=9000, seed=6)]
+    full = synthetic.fixture_atmosphere()
+    atmos = synthetic.Atmos(p=full.p, t=full.t, vmr={k: full.vmr[k] for k in ("H2O", "CO2")})
+    grid = np.arange(606., 670., 0.001)
+    results = {}
+    for farfield in (True, False):
+        spec = Spectroscopy(atmos, grid, MemoryDatabase(tables), continua_backend=None,
+                            cross_sections_backend=None, farfield=farfield)
+        assert spec.farfield is farfield
+        for fmt in ("all", "gas", "total"):
+            results[(farfield, fmt)] = spec.compute_absorption(fmt, remove_pedestal=True)
+    for fmt, names in (("all", ("H2O_absorption", "CO2_absorption")),
+                       ("gas", ("H2O_absorption", "CO2_absorption")), ("total", ("absorption",))):
+        for name in names:
+            series, direct = results[(True, fmt)][name], results[(False, fmt)][name]
+            assert series.shape == direct.shape and not np.array_equal(series, direct)
+            flat = direct.reshape(direct.shape[0], -1)          # per level, every slot
+            scale = np.max(np.abs(flat), axis=1, keepdims=True)
+            assert np.max(np.abs(series.reshape(flat.shape) - flat)/scale) < 1.e-9, (fmt, name)
+    engine = spec._molecule("CO2").gas.engine
+    idle = sum(len(blocks) for blocks in engine.blocks.idle.values())
+    assert idle >= 1
+    before = engine.blocks.idle_bytes
+    spec.compute_absorption("total")
+    assert engine.blocks.idle_bytes == before          # taken from the pool, handed back

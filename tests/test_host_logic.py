@@ -221,3 +221,32 @@ def test_bench_closed_form_eval_count_matches_oracle(oracle):
         table = synthetic.line_table("CO2", lo, hi, num_lines=400, seed=seed, tips_range=(150, 400))
         _, extras = oracle.absorption_port(table, 250., 5.e4, 3.6e-4, v0, vn, npv)
         assert bench.closed_form_evals(table, 5.e4, v0, vn, npv) == extras["evals"]
+
+
+def test_memory_database_mirrors_the_file_backed_one(tmp_path):
+    """MemoryDatabase: the read surface Spectroscopy and Gas use, over tables held in memory."""
+    tables = [synthetic.line_table("H2O", 1., 100., num_lines=50, seed=1, tips_range=(150, 350)),
+              synthetic.line_table("CO2", 1., 100., num_lines=40, seed=2, tips_range=(150, 350))]
+    memory = database.MemoryDatabase(tables, aliases={"H2O": ["water"]})
+    on_disk = database.Database(database.write_database(tmp_path / "lines.db", tables,
+                                                        aliases={"H2O": ["water"]}))
+    assert memory.path is None and memory.molecules() == on_disk.molecules()
+    for name in ("H2O", "water", "CO2"):
+        a, b = memory.line_table(name), on_disk.line_table(name)
+        for column in database.LINE_COLUMNS:
+            assert np.array_equal(getattr(a, column), getattr(b, column))
+        assert np.array_equal(memory.tips(name)[1], on_disk.tips(name)[1])
+        assert memory.gas(name).mass == on_disk.gas(name).mass
+    with pytest.raises(AliasNotFoundError):
+        memory.line_table("XYZ")
+
+
+def test_partition_function_object_checks_its_shape():
+    with pytest.raises(ValueError):
+        database.TotalPartitionFunction("H2O", np.arange(3.), np.zeros((2, 4)))
+    tips = database.TotalPartitionFunction("H2O", np.asarray([100., 101., 102.]),
+                                           np.asarray([[1., 3., 7.]]))
+    assert tips.isotopologue == [0]
+    assert tips.total_partition_function(101.25, 1) == pytest.approx(4.)
+    # An exact table temperature takes the interval below it (the reference's left-sided search).
+    assert tips.total_partition_function(101., 1) == pytest.approx(3.)
