@@ -73,6 +73,8 @@ def parse():
     parser.add_argument("--banded", action="store_true",
                         help="banded line tables (same counts) instead of uniform ones")
     parser.add_argument("--points-per-lane", type=int, default=0)
+    parser.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                        help="lbl_set_option before anything is computed (experiments)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-extras", action="store_true",
                         help="only the timed steps (what scripts/profile_bench.sh profiles)")
@@ -592,6 +594,9 @@ def main():
     engine = Engine(device_index)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
+    for pair in args.engine_option:
+        name, value = pair.split("=")
+        engine.set_option(name, int(value))
     if args.farfield:
         engine.set_option("farfield", 1)
     if args.ablate:

@@ -563,13 +563,16 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
                     std::lower_bound(nu.begin(), nu.end(), lo);
         total += weight[t];
     }
-    // Aim for ~16 items per workgroup slot of the chip (256 CUs x ~5 resident workgroups),
-    // but never items smaller than 512 lines.
-    // On small grids (a launch does not fill the chip; every scalar load is a miss) short
-    // chains of lines per wavefront matter more than the per-item overhead: 128-line items.
+    // Aim for ~8 items per workgroup slot of the chip (256 CUs x 6 resident workgroups): enough
+    // rounds that the last one costs little, few enough that uniform tables leave their tiles
+    // whole -- every extra item pays the kernel's prologue again and every split tile a pass
+    // of combine_kernel (A/B on the 5 M-point workloads: 2-3 % against items half that size).
+    // Dense bands still get their heavy tiles cut.  On small grids (a launch does not fill the
+    // chip; every scalar load is a miss) short chains of lines per wavefront matter more than the
+    // per-item overhead: items down to 128 lines.
     const long long floor_lines = engine->item_floor > 0 ? engine->item_floor
                                   : (n_tiles < 1024 || farfield) ? 128 : 512;
-    const long long target = std::max<long long>(floor_lines, total/(16*1280) + 1);
+    const long long target = std::max<long long>(floor_lines, total/(8*1536) + 1);
     std::vector<WorkItem> items;
     std::vector<SplitTile> split;
     std::vector<long long> item_weight;
