@@ -6,8 +6,8 @@ tests/test_oracle_golden.py) does ~1.2e9 evaluations per second and core, so who
 the host cores (tests/oracle_farm.py).  All jobs are queued when the first test of this file
 starts and run beside the GPU work of the others.
 
-What is compared (labels contain "baseline"; none of them may need the growth-scaled
-pedestal tolerance, see test_gpu_zz_tolerance_report.py):
+What is compared (labels contain "baseline"; none of them may need the conditioning
+allowance for the pedestal, see test_gpu_zz_tolerance_report.py):
 
   configs[0]  CO2, 500-800 @ 0.1: the bench's in-range table AND a 1-5000 table whose first
               row lies below 474 cm-1, so the reference's range `break` (absorption.c:80-83)

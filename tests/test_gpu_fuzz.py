@@ -8,7 +8,7 @@ import pytest
 
 from pylbl_amd import synthetic
 from tests import golden_io
-from tests.test_gpu_parity import assert_spectrum
+from tests.test_gpu_parity import assert_spectrum, oracle_conditioning
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,10 @@ def test_random_case(engine, oracle, seed):
             assert_spectrum(got[level], k_ref, case,
                             f"seed {seed} level {level}: v0={v0} vn={vn} npv={npv} cut={cut} "
                             f"lines={c['n_lines']} ped={ped} policy={policy} p={p[level]:.3g}",
-                            k_plain)
+                            k_plain,
+                            conditioning=lambda: oracle_conditioning(
+                                oracle, source, t[level], p[level], x[level], v0, vn, npv, cut,
+                                k_ref))
     finally:
         engine.free(molecule)
         for name, value in (("farfield", 0), ("prep", 0), ("points_per_lane", 0),

@@ -9,7 +9,7 @@ import pytest
 
 from pylbl_amd import synthetic
 from tests import golden_io
-from tests.test_gpu_parity import assert_spectrum
+from tests.test_gpu_parity import assert_spectrum, oracle_conditioning
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,10 @@ def test_random_large_case(engine, oracle, seed):
             case = golden_io.Case("large", seed, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
             assert_spectrum(got[level], k_ref, case,
                             f"seed {seed} level {level}: v0={v0} span={span} npv={npv} cut={cut} "
-                            f"lines={table.num_lines} ped={ped} p={p[level]:.3g}", k_plain)
+                            f"lines={table.num_lines} ped={ped} p={p[level]:.3g}", k_plain,
+                            conditioning=(lambda: oracle_conditioning(
+                                oracle, table, t[level], p[level], x[level], v0, vn, npv, cut,
+                                k_ref)) if ped else None)
     finally:
         engine.free(molecule)
         for name, value in (("farfield", 0), ("points_per_lane", 0), ("scan_chain", 1)):

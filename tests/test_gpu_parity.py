@@ -20,24 +20,38 @@ def engine():
 
 # Every pedestal comparison that needed more than the plain SURVEY 8(c) metric leaves a record
 # here; tests/test_gpu_zz_tolerance_report.py prints them and bounds their number.
-GROWTH_CAP = 100.
-TOLERANCE_LOG = {"compared": 0, "scaled": [], "baseline": []}
+CONDITIONING_MARGIN = 100.
+TOLERANCE_LOG = {"compared": 0, "conditioned": [], "baseline": []}
 
 
-def assert_spectrum(k, k_ref, case, label, k_plain=None):
+def oracle_conditioning(oracle, table, t, p, x, v0, vn, npv, cut, k_ref):
+    """How far the REFERENCE's own pedestal result moves when every line strength is changed by
+    at most one unit in the last place: |k_ref(perturbed) - k_ref| per point.  The recurrence
+    k -= min(k[first], k[last]) (spectra.c:66-78) is linear with coefficients of magnitude one;
+    with line centres on window edges (the fuzz puts lines on integer wavenumbers) it amplifies
+    last-bit differences by many orders of magnitude, and this is the direct measure of it."""
+    rng = np.random.default_rng(12345)
+    perturbed = table.subset(np.ones(table.num_lines, bool))
+    perturbed.sw = table.sw*(1. + rng.integers(-1, 2, table.num_lines)*2.**-52)
+    moved, _ = oracle.absorption_port(perturbed, t, p, x, v0, vn, npv, cut_off=cut,
+                                      remove_pedestal=True)
+    return np.abs(moved - k_ref)
+
+
+def assert_spectrum(k, k_ref, case, label, k_plain=None, conditioning=None):
     """k_plain (optional): the reference spectrum WITHOUT pedestal removal.  With the pedestal
     removed a value is (sum of profiles) - (sum of pedestals); where the two cancel (the
     reference produces exact zeros there) the meaningful scale of an error is the size of the
     cancelling terms, i.e. k_plain, not the vanishing difference.
 
-    The reference's recurrence k -= min(k[first], k[last]) is linear with coefficients of
-    magnitude one, and when line centres sit on window edges (the fuzz puts lines exactly on
-    integer wavenumbers at near-vacuum pressure) it amplifies: |k| grows beyond anything in
-    the un-pedestalled spectrum, and the last-bit differences between two correct fp64
-    evaluations of the profiles grow by the same factor (found by a 2000-case soak: 1.03e-6 of
-    the local maximum after 2843 such lines, rising smoothly with the number of rows).  The
-    tolerance is scaled by that growth, max|k_ref| / max|k_plain|, where it exceeds one -- but
-    never by more than GROWTH_CAP, and every case that needed the scaling is logged."""
+    conditioning (optional): callable returning oracle_conditioning(...) for this case.  Two
+    correct fp64 evaluations of the profiles differ by a few units in the last place (here:
+    reciprocal + Newton step instead of division, another summation order); where the
+    reference's recurrence amplifies such differences beyond the plain tolerance -- found by
+    soaks of the seeded fuzz, rising smoothly with the number of rows, identical in every build
+    of the engine -- the comparison may use CONDITIONING_MARGIN x the largest movement of the
+    reference itself under a one-ulp perturbation of its inputs within a line window.  It is
+    only consulted when the plain metric fails, and every case that needed it is logged."""
     assert k.shape == k_ref.shape
     if case.remove_pedestal:
         tol = golden_io.pedestal_tolerance(k_ref, case.n_per_v, case.cut_off, REL)
@@ -51,20 +65,19 @@ def assert_spectrum(k, k_ref, case, label, k_plain=None):
             # un-pedestalled value within a window is far below anything that carries meaning.
             tol = np.maximum(tol, golden_io.pedestal_tolerance(k_plain, case.n_per_v,
                                                                case.cut_off, 1.e-13))
-            growth = np.max(np.abs(k_ref))/max(np.max(np.abs(k_plain)), 1e-300)
-            if growth > 1.:
-                unscaled = float(np.max(np.abs(k - k_ref)/(tol + 1e-300)))
-                if unscaled > 1.:
-                    # Only cases that actually need the scaling are logged and scaled.
-                    factor = min(growth, GROWTH_CAP)
-                    TOLERANCE_LOG["scaled"].append(
-                        {"label": label, "growth": float(growth), "factor": float(factor),
-                         "worst_unscaled": unscaled})
-                    tol = tol*factor
-        tol += 1e-300
-        worst = np.max(np.abs(k - k_ref)/tol)
+        tol = tol + 1e-300
+        worst = float(np.max(np.abs(k - k_ref)/tol))
+        if worst > 1. and conditioning is not None:
+            moved = conditioning()
+            allowance = golden_io.pedestal_tolerance(moved, case.n_per_v, case.cut_off,
+                                                     CONDITIONING_MARGIN)
+            conditioned = float(np.max(np.abs(k - k_ref)/(tol + allowance)))
+            TOLERANCE_LOG["conditioned"].append(
+                {"label": label, "worst_plain": worst, "worst_conditioned": conditioned,
+                 "reference_moves_by": float(np.max(moved)/max(np.max(np.abs(k_ref)), 1e-300))})
+            worst = conditioned
         if label.startswith("baseline"):
-            TOLERANCE_LOG["baseline"].append((label, k.size, float(worst), "x pedestal tolerance"))
+            TOLERANCE_LOG["baseline"].append((label, k.size, worst, "x pedestal tolerance"))
         assert worst <= 1., f"{label}: {worst:.3g} x the pedestal tolerance"
     else:
         nz = k_ref != 0
