@@ -451,8 +451,19 @@ __global__ __launch_bounds__(256) void combine_kernel(const AccumulateArgs a,
     if (i > last_point) return;
     const double * slot = a.partial + ((long long)level*a.partial_slots + t.slot)*points +
                           p*64 + lane;
+    // Same order of additions as a plain loop over the parts; the loads of eight parts are issued
+    // together (on small grids every one of them is a miss).
     double value = 0.;
-    for (int part = 0; part < t.parts; ++part)
+    int part = 0;
+    for (; part + 8 <= t.parts; part += 8)
+    {
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = slot[(long long)(part + j)*points];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) value += x[j];
+    }
+    for (; part < t.parts; ++part)
     {
         value += slot[(long long)part*points];
     }
