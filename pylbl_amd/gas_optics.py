@@ -17,23 +17,24 @@ from .synthetic import grid_arguments
 
 
 class Gas(object):
-    """API for gas optics calculation.
+    """One molecule's line-by-line absorption on an MI355X: the lines backend that
+    ``molecular_lines["mi355x"]`` names (same shape as pyLBL/c_lib/gas_optics.py:29-44).
 
     Attributes:
-        database: String path to the spectral sqlite3 database.
-        formula: String chemical formula.
-        engine: pylbl_amd.engine.Engine the line table lives on.
-        molecule: Engine handle of the resident line table (None: nothing to compute).
+        database: path of the SQLite file the lines came from (None for an in-memory table).
+        formula: the molecule, e.g. "CO2".
+        engine: pylbl_amd.engine.Engine whose HBM holds the line table.
+        molecule: the engine's handle of that table (None: no lines or no partition sums).
     """
     def __init__(self, lines_database, formula, device=0, engine=None):
-        """Initializes the object.
+        """Reads the molecule's transitions, masses and partition sums once and uploads them.
 
         Args:
-            lines_database: Database object (``.path``, ``.line_table(formula)``), or a
-                            pylbl_amd.database.LineTable to upload directly.
-            formula: String chemical formula.
+            lines_database: anything with ``.path`` and ``.line_table(formula)`` (Database,
+                            MemoryDatabase), or a pylbl_amd.database.LineTable itself.
+            formula: the molecule, e.g. "CO2" (any alias the database knows).
             device: GPU index.
-            engine: Optional Engine to share (default: the process-wide one per device).
+            engine: an Engine to share; by default the process-wide one of `device`.
         """
         self.formula = formula
         self.engine = engine if engine is not None else default_engine(device)
@@ -63,21 +64,20 @@ class Gas(object):
 
     def absorption_coefficient(self, temperature, pressure, volume_mixing_ratio, grid,
                                remove_pedestal=False, cut_off=25, range_policy="reference"):
-        """Calculates absorption coefficient.
+        """Absorption cross-section spectrum of one level (signature of
+        pyLBL/c_lib/gas_optics.py:46-47; one level of ``absorption_coefficients``).
 
         Args:
-            temperature: Temperature [K].
-            pressure: Pressure [Pa].
-            volume_mixing_ratio: Volume mixing ratio [mol mol-1].
-            grid: Numpy array defining the spectral grid [cm-1].
-            remove_pedestal: Flag specifying if a pedestal should be subtracted.
-            cut_off: Wavenumber cut-off distance [cm-1] from line centers.
+            temperature [K], pressure [Pa], volume_mixing_ratio [mol mol-1]: the level.
+            grid: wavenumbers [cm-1]; must start on an integer with spacing 1/integer.
+            remove_pedestal: subtract the running pedestal of spectra.c:66-78.
+            cut_off: half-width [cm-1] of every line's window.
             range_policy: "reference" stops at the first row outside the grid +- (cut_off+1)
                           like absorption.c:80-83; "skip" ignores such rows.
 
         Returns:
-            Numpy array of absorption coefficients [m2]; like the reference it holds
-            (vn - v0)*n_per_v >= grid.size points, callers slice [:grid.size].
+            float64 array [m2 molecule-1] of (vn - v0)*n_per_v >= grid.size points, as the
+            reference returns it; callers slice [:grid.size].
         """
         return self.absorption_coefficients([temperature], [pressure], [volume_mixing_ratio],
                                             grid, remove_pedestal, cut_off, range_policy)[0]

@@ -18,8 +18,15 @@ def main():
     from pylbl_amd.engine import Engine
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     n_levels, output = int(sys.argv[1]), sys.argv[2]
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    # DIST_BACKEND=nccl (RCCL): one GPU per rank; default gloo with every rank on GPU 0.
+    backend = os.environ.get("DIST_BACKEND", "gloo")
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     formulas = ("H2O", "CO2", "O3")
     tables = {f: synthetic.line_table(f, 600., 700., num_lines=500 + 300*i, seed=31 + i)
               for i, f in enumerate(formulas)}
@@ -27,7 +34,7 @@ def main():
     t, p = atmos.t[:n_levels], atmos.p[:n_levels]
     vmr = {f: atmos.vmr[f][:n_levels] for f in formulas}
     v0, vn, npv = 610, 650, 200
-    engine = Engine(0)
+    engine = Engine(device)
     handles = {f: engine.load(tables[f]) for f in formulas}
     sharded = distributed.ShardedLines.for_engine(
         engine, handles, (v0, vn, npv), remove_pedestal=True, scale_density=(output == "total"),
@@ -66,11 +73,11 @@ def main():
         atm = synthetic.Atmos(p=p.reshape(1, -1), t=t.reshape(1, -1),
                               vmr={f: x.reshape(1, -1) for f, x in vmr.items()})
         for fmt in ("all", "gas", "total"):
-            sharded_out = Spectroscopy(atm, grid, db, group=True).compute_absorption(fmt)
+            sharded_out = Spectroscopy(atm, grid, db, group=True, device=device).compute_absorption(fmt)
             if rank != 0:
                 assert sharded_out is None
                 continue
-            whole = Spectroscopy(atm, grid, db).compute_absorption(fmt)
+            whole = Spectroscopy(atm, grid, db, device=device).compute_absorption(fmt)
             assert set(whole) == set(sharded_out)
             for name in whole:
                 if name.endswith("absorption"):

@@ -49,17 +49,14 @@ def test_for_engine_single_rank_against_oracle(oracle, output):
     engine.close()
 
 
-@pytest.mark.parametrize("n_levels,output", [(5, "gas"), (1, "gas"), (1, "total"), (4, "total")])
-def test_two_ranks_share_one_gpu(n_levels, output):
-    """Levels >= ranks shards levels; one level shards its three molecules over the two ranks
-    (and the total then needs the cross-rank sum)."""
+def _run_ranks(n_levels, output, backend):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), DIST_BACKEND=backend)
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(n_levels),
              output], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -71,3 +68,20 @@ def test_two_ranks_share_one_gpu(n_levels, output):
                 other.kill()
             raise
         assert proc.returncode == 0 and f"rank {rank} ok" in out, out + err[-3000:]
+
+
+@pytest.mark.parametrize("n_levels,output", [(5, "gas"), (1, "gas"), (1, "total"), (4, "total")])
+def test_two_ranks_share_one_gpu(n_levels, output):
+    """Levels >= ranks shards levels; one level shards its three molecules over the two ranks
+    (and the total then needs the cross-rank sum)."""
+    _run_ranks(n_levels, output, "gloo")
+
+
+@pytest.mark.parametrize("n_levels,output", [(5, "gas"), (1, "total")])
+def test_two_gpus_over_rccl(n_levels, output):
+    """The same checks with one GPU per rank and RCCL carrying the exchange (backend "nccl"):
+    runs wherever two GPUs are visible -- the single-GPU test boxes skip it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_ranks(n_levels, output, "nccl")
