@@ -144,8 +144,13 @@ struct Lane
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
     hipEvent_t runs_found = nullptr;
     hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
-    hipEvent_t finished = nullptr;  // end of the last call that wrote device output on this lane
-    const char * out_begin = nullptr, * out_end = nullptr;     // ... and where it wrote
+    // The last few writes of device output queued on this lane: where, and an event behind the
+    // kernel that wrote.  A call on another lane that touches the same memory waits for it.
+    struct Write { const char * begin = nullptr; const char * end = nullptr; hipEvent_t done = nullptr; };
+    static constexpr int kWrites = 4;
+    Write writes[kWrites];
+    int next_write = 0;
+    bool writes_wrapped = false;
     bool used = false;              // something was queued here since lane 0 last joined it
     bool levels_in_flight = false;
     DeviceBuffer<LineWing> wing;
@@ -173,7 +178,7 @@ struct Lane
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&finished, hipEventDisableTiming));
+        for (auto & w : writes) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
     }
@@ -191,7 +196,7 @@ struct Lane
         if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
         if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
         if (queued != nullptr) (void)hipEventDestroy(queued);
-        if (finished != nullptr) (void)hipEventDestroy(finished);
+        for (auto & w : writes) { if (w.done != nullptr) (void)hipEventDestroy(w.done); w.done = nullptr; }
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
         if (side != nullptr) (void)hipStreamDestroy(side);
@@ -205,6 +210,16 @@ struct Lane
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_levels),
                               count*sizeof(LevelScalars), hipHostMallocDefault));
         pinned_capacity = count;
+    }
+    // Everything queued on `stream` (this lane's) so far has written [begin, end).
+    void note_write(const void * begin, long long bytes, hipStream_t stream)
+    {
+        Write & w = writes[next_write];
+        w.begin = reinterpret_cast<const char *>(begin);
+        w.end = w.begin + bytes;
+        HIP_TRY(hipEventRecord(w.done, stream));
+        next_write = (next_write + 1) % kWrites;
+        if (next_write == 0) writes_wrapped = true;
     }
 };
 
@@ -374,6 +389,31 @@ struct lbl_engine
     {
         for (auto & lane : lanes) lane.drain();
         if (copy_stream != nullptr) (void)hipStreamSynchronize(copy_stream);
+    }
+
+    // Orders `stream` (a stream of lane `self`) behind every write of [begin, begin + bytes) queued
+    // on the other lanes.  Each lane remembers its last few writes; older ones were queued before
+    // the oldest it remembers, whose event therefore stands in for them.
+    void order_after_writers(hipStream_t stream, const void * begin, long long bytes,
+                             const Lane * self)
+    {
+        const char * b = reinterpret_cast<const char *>(begin);
+        const char * e = b + bytes;
+        for (auto & lane : lanes)
+        {
+            if (&lane == self) continue;
+            for (const auto & w : lane.writes)
+            {
+                if (w.begin != nullptr && b < w.end && w.begin < e)
+                {
+                    HIP_TRY(hipStreamWaitEvent(stream, w.done, 0));
+                }
+            }
+            if (lane.writes_wrapped)
+            {
+                HIP_TRY(hipStreamWaitEvent(stream, lane.writes[lane.next_write].done, 0));
+            }
+        }
     }
 
     // Orders `stream` (lane 0's) behind everything queued on the other lanes so far, without
@@ -698,11 +738,16 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         // it almost idle); plain calls run back to back on lane 0.
         // Small grids (a launch does not fill the chip, latency rules) gain the same way.
         const bool small = n_long*rq.n_levels <= (1ll << 16);
-        const bool alternate = (rq.flags & LBL_ASYNC) && !(rq.flags & LBL_ACCUMULATE) &&
-                               want_k && rq.derived == nullptr &&
-                               (rq.remove_pedestal || (small && out_device));
+        // A call that adds into its output can share the GPU too when it removes the pedestal:
+        // only its last kernel (pedestal_apply_kernel) touches the output, everything before
+        // works in the lane's own buffers.
+        const bool add_into_block = (rq.flags & LBL_ACCUMULATE) != 0;
+        const bool alternate = (rq.flags & LBL_ASYNC) && want_k && rq.derived == nullptr &&
+                               ((rq.remove_pedestal && (!add_into_block || out_device)) ||
+                                (small && out_device && !add_into_block));
         Lane & lane = engine->lanes[alternate ? (engine->next_lane++ % kLanes) : 0];
         hipStream_t stream = lane.main;
+        const long long out_bytes = ((long long)(rq.n_levels - 1)*stride + n_long)*8;
         if (!alternate)
         {
             if ((rq.flags & LBL_ASYNC) && out_device)
@@ -717,20 +762,12 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         else
         {
             lane.used = true;
-        }
-        if (alternate && out_device)
-        {
-            // Calls on different lanes run side by side; two that write the same memory must
-            // not: the later one waits for the earlier one's last kernel.
-            const char * begin = reinterpret_cast<const char *>(rq.k);
-            const char * end = begin + ((long long)(rq.n_levels - 1)*stride + n_long)*8;
-            for (auto & other : engine->lanes)
+            if (out_device && !add_into_block)
             {
-                if (&other != &lane && other.out_begin != nullptr && begin < other.out_end &&
-                    other.out_begin < end)
-                {
-                    HIP_TRY(hipStreamWaitEvent(stream, other.finished, 0));
-                }
+                // Calls on different lanes run side by side; two that write the same memory must
+                // not: the later one waits for the earlier one's last kernel.  (A call that adds
+                // into the block waits later, in front of the one kernel that does the adding.)
+                engine->order_after_writers(stream, rq.k, out_bytes, &lane);
             }
         }
 
@@ -965,6 +1002,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                     HIP_TRY(hipEventRecord(lane.pedestal_done, lane.side));
                     HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
                 }
+                if (alternate && out_device && add_into)
+                {
+                    engine->order_after_writers(stream, rq.k, out_bytes, &lane);
+                }
                 dim3 grid((unsigned)((n_long + 255)/256), (unsigned)count);
                 hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, stream, sums,
                                    sums_stride, target, target_stride,
@@ -1009,9 +1050,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
 
         if (out_device && want_k)
         {
-            HIP_TRY(hipEventRecord(lane.finished, stream));
-            lane.out_begin = reinterpret_cast<const char *>(rq.k);
-            lane.out_end = lane.out_begin + ((long long)(rq.n_levels - 1)*stride + n_long)*8;
+            lane.note_write(rq.k, out_bytes, stream);
         }
         if (rq.evals != nullptr && !(engine->prep == LBL_PREP_HOST))
         {
@@ -1429,6 +1468,7 @@ int lbl_fill_zero(lbl_engine * engine, double * k, int32_t n_levels, int64_t n,
         for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
         HIP_TRY(hipMemset2DAsync(k, (size_t)stride*8, 0, (size_t)n*8, (size_t)n_levels,
                                  engine->stream));
+        engine->lanes[0].note_write(k, ((long long)(n_levels - 1)*stride + n)*8, engine->stream);
         if (!(flags & LBL_ASYNC)) HIP_TRY(hipStreamSynchronize(engine->stream));
     }
     catch (const HipFailure & f)
