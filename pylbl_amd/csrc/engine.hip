@@ -3,10 +3,13 @@
 // Replaces the body of the reference's absorption() (pyLBL/c_lib/absorption.c:19-99):
 //   * the per-call SQLite read (absorption.c:44-73) becomes a one-time upload of a
 //     wavenumber-sorted struct-of-arrays line table (lbl_molecule_load);
-//   * the row loop calling spectra()/voigt() (absorption.c:76-86) becomes three kernel
-//     launches per batch of levels: prepare_kernel (per-line scalars), schedule_kernel
-//     (per-tile cut points) and accumulate_kernel (the Voigt sums), plus the pedestal
-//     kernels when remove_pedestal is set.
+//   * the row loop calling spectra()/voigt() (absorption.c:76-86) becomes two kernel launches
+//     per batch of levels -- prologue_kernel (per-line scalars and per-tile cut points) and
+//     accumulate_kernel (the Voigt sums; combine_kernel after it where tiles were split) --
+//     plus the pedestal kernels when remove_pedestal is set.
+// Calls may be queued without waiting (LBL_ASYNC): the engine has several "lanes" (stream pair +
+// workspace); calls that can share the GPU rotate over them and are ordered against each other
+// only through the memory they write (Lane::note_write, lbl_engine::order_after_writers).
 // There is no CPU compute path in this file: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
@@ -732,10 +735,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
-        // Asynchronous calls alternate between the two lanes; anything that adds into its
-        // output, or that the caller waits for, takes lane 0 with the other lane idle.
-        // Only calls with a pedestal gain from sharing the GPU (their serial chain leaves
-        // it almost idle); plain calls run back to back on lane 0.
+        // Asynchronous calls rotate over the lanes where sharing the GPU pays: calls with a
+        // pedestal (their serial chain leaves it almost idle) and calls on small grids; plain
+        // calls on large grids run back to back on lane 0, behind everything the other lanes
+        // hold, as does anything the caller waits for.
         // Small grids (a launch does not fill the chip, latency rules) gain the same way.
         const bool small = n_long*rq.n_levels <= (1ll << 16);
         // A call that adds into its output can share the GPU too when it removes the pedestal:
