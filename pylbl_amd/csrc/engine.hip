@@ -170,13 +170,20 @@ struct Lane
     LevelScalars * pinned_levels = nullptr;
     size_t pinned_capacity = 0;
 
-    void create()
+    void create(bool urgent = false)
     {
-        HIP_TRY(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
         // The pre-pass is short and latency-bound (a serial chain): its queue goes first
         // whenever the accumulate grid frees a slot.
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (urgent)
+        {
+            HIP_TRY(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, greatest));
+        }
+        else
+        {
+            HIP_TRY(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+        }
         HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
@@ -226,7 +233,13 @@ struct Lane
     }
 };
 
-constexpr int kLanes = 8;
+constexpr int kLanes = 8;           // lanes the lines calls rotate over
+// One more lane carries the continuum and cross-section calls: short, bandwidth-bound kernels
+// on a stream of the highest priority, so that they are dispatched as soon as workgroup slots
+// free up instead of queueing behind a resident accumulate grid of another lane (a 6 us
+// band_spectra_kernel was seen waiting 0.9 ms for one).
+constexpr int kSlotLane = kLanes;
+constexpr int kAllLanes = kLanes + 1;
 
 // Level scalars of a batched call on their way to the device: a pinned block, its device
 // copy and an event that marks the last kernel reading them (and the per-level workspace that
@@ -321,7 +334,7 @@ struct lbl_engine
     std::vector<std::unique_ptr<ContinuumSet>> continua;
     std::vector<std::unique_ptr<SpectralGrid>> grids;
     std::vector<std::unique_ptr<XsecData>> xsecs;
-    Lane lanes[kLanes];
+    Lane lanes[kAllLanes];
     unsigned next_lane = 0;
 
     // Options.
@@ -424,7 +437,7 @@ struct lbl_engine
     // that rotated over the lanes, needs.
     void join_lanes(hipStream_t stream)
     {
-        for (int i = 1; i < kLanes; ++i)
+        for (int i = 1; i < kAllLanes; ++i)
         {
             if (!lanes[i].used) continue;
             HIP_TRY(hipEventRecord(lanes[i].queued, lanes[i].main));
@@ -759,7 +772,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
             else
             {
-                for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+                for (int i = 1; i < kAllLanes; ++i) engine->lanes[i].drain();
             }
         }
         else
@@ -1130,7 +1143,7 @@ int lbl_engine_create(int device, lbl_engine ** engine)
         HIP_TRY(hipSetDevice(device));
         std::unique_ptr<lbl_engine> e(new lbl_engine());
         e->device = device;
-        for (auto & lane : e->lanes) lane.create();
+        for (int i = 0; i < kAllLanes; ++i) e->lanes[i].create(i == kSlotLane);
         e->stream = e->lanes[0].main;
         HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         *engine = e.release();
@@ -1468,7 +1481,7 @@ int lbl_fill_zero(lbl_engine * engine, double * k, int32_t n_levels, int64_t n,
     {
         HIP_TRY(hipSetDevice(engine->device));
         // Ordered like a plain compute call: after everything queued on the other lanes.
-        for (int i = 1; i < kLanes; ++i) engine->lanes[i].drain();
+        for (int i = 1; i < kAllLanes; ++i) engine->lanes[i].drain();
         HIP_TRY(hipMemset2DAsync(k, (size_t)stride*8, 0, (size_t)n*8, (size_t)n_levels,
                                  engine->stream));
         engine->lanes[0].note_write(k, ((long long)(n_levels - 1)*stride + n)*8, engine->stream);
