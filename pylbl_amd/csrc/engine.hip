@@ -349,6 +349,7 @@ struct lbl_engine
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
+    int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };
@@ -981,7 +982,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             args.accumulate = (!with_pedestal && out_device && add_into) ? 1 : 0;
             args.ablate = engine->ablate;
 
-            if (with_pedestal && engine->overlap_pedestal)
+            if (with_pedestal && engine->overlap_pedestal && engine->order_runs)
             {
                 HIP_TRY(hipStreamWaitEvent(stream, lane.runs_found, 0));
             }
@@ -1356,6 +1357,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "scan_chain" && (value == 0 || value == 1))
     {
         engine->scan_chain = (int)value;
+    }
+    else if (key == "order_runs" && (value == 0 || value == 1))
+    {
+        engine->order_runs = (int)value;
     }
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {

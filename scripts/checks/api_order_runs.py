@@ -1,0 +1,18 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+os.environ.setdefault("PYLBL_MT_CKD", os.path.join(sys.path[0], "tests", "golden", "mt_ckd_bands.npz"))
+from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic, default_engine
+tables = [synthetic.line_table(f, 1., 5000.) for f in ("H2O", "CO2")]
+s = synthetic.surface_level()
+level = synthetic.Atmos(p=s.p, t=s.t, vmr={f: s.vmr[f] for f in ("H2O", "CO2")})
+grid = np.arange(1., 5000., 0.001)
+spec = Spectroscopy(level, grid, MemoryDatabase(tables))
+for rounds in range(2):
+    for order in (1, 0):
+        default_engine(0).set_option("order_runs", order)
+        for fmt in ("total", "gas"):
+            for _ in range(4): spec.compute_absorption(fmt)
+            t = time.perf_counter()
+            for _ in range(20): spec.compute_absorption(fmt)
+            print(f"order_runs={order} {fmt}: {(time.perf_counter()-t)/20*1e3:.2f} ms")
