@@ -132,6 +132,24 @@ class _Sum(object):
         return self
 
 
+def _zero_in_background(views):
+    """Zeroes float64 [rows, columns] views with contiguous rows on a helper thread (ctypes
+    releases the interpreter lock during memset); returns the started thread, or None."""
+    if not views:
+        return None
+    import ctypes
+    import threading
+
+    def fill():
+        for view in views:
+            row_bytes = view.shape[1]*8
+            for row in range(view.shape[0]):
+                ctypes.memset(view[row].ctypes.data, 0, row_bytes)
+    thread = threading.Thread(target=fill)
+    thread.start()
+    return thread
+
+
 class Spectroscopy(object):
     """Line-by-line gas optics (lines, MT-CKD continua, ARTS-crossfit cross-sections) on an
     MI355X.
@@ -259,6 +277,7 @@ class Spectroscopy(object):
         # all levels, n*k applied in the kernel epilogue, spectra left in HBM until the end;
         # the sums over mechanisms ("gas") and over gases ("total") happen on the device.
         blocks = {}             # (gas, mechanism) -> host array (only when too large for HBM)
+        zero_fills = []         # row views of results that no mechanism writes
         results = {}            # gas -> its finished array, being filled by queued copies
         in_flight = []          # blocks in HBM to release once everything has arrived
         total = None
@@ -325,7 +344,9 @@ class Spectroscopy(object):
                 values = engine.host_array([levels, len(MECHANISMS), columns])
                 for slot, block in enumerate((lines_sum, continuum_sum, cross_sum)):
                     if block is None:
-                        values[:, slot, :] = 0.
+                        # An empty mechanism slot reads zero (40 MB per level at 5 M points):
+                        # filled by a helper thread beside the queueing and the kernels.
+                        zero_fills.append(values[:, slot, :])
                     else:
                         in_flight.append(block.into(values[:, slot, :]))
                 results[name] = values
@@ -335,8 +356,11 @@ class Spectroscopy(object):
         if mode == "total" and total is not None:
             results["total"] = engine.host_array((levels, columns))
             in_flight.append(total.into(results["total"]))
+        filler = _zero_in_background(zero_fills)
         if engine is not None:
             engine.synchronize()
+        if filler is not None:
+            filler.join()
         for block in in_flight:
             engine.blocks.give(block.buffer)
 
