@@ -24,7 +24,6 @@ for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure w
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

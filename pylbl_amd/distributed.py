@@ -254,7 +254,9 @@ class ShardedLines(object):
 
         Returns:
             On rank `dst` (every rank if dst is None) the result, elsewhere None (dict of None
-            for "gas"); or a Pending that yields it.
+            for "gas"); or a Pending that yields it.  With one rank the tensors returned are the
+            rank's own blocks, of which there are two sets used in turn: they keep their contents
+            until the call after next (copy what must live longer).
         """
         import torch
         import torch.distributed as dist

@@ -19,7 +19,7 @@ import numpy as np
 
 from .errors import AliasNotFoundError, CrossSectionNotFoundError, \
                     IsotopologuesNotFoundError, TipsDataNotFoundError, TransitionsNotFoundError
-from .engine import DeviceSpectra
+
 from .plugins import continua, cross_sections, molecular_lines
 from .synthetic import grid_arguments
 
