@@ -1,0 +1,62 @@
+"""bench.py's contract with the driver, checked on the GPU: one JSON line with the agreed keys,
+a roofline fraction in (0, 1], a CPU baseline, and the same record from the two-rank launch
+(gloo, both ranks on GPU 0: the flow the driver starts with torch.distributed.run over RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+        "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def run(command):
+    result = subprocess.run(command, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [x for x in result.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, result.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check(line, n_gpus, steps, warmup):
+    assert KEYS <= set(line)
+    assert line["n_gpus"] == n_gpus and line["steps"] == steps and line["warmup"] == warmup
+    assert line["unit"] == "evals/s" and line["dtype"] == "f64" and line["data"] == "synthetic"
+    assert line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["value"] > 1.e9*n_gpus               # north_star's floor, per GPU
+    assert abs(line["value"] - line["evals_per_step"]*steps/(line["ms_per_step"]*1e-3*steps)) \
+        <= 1e-6*line["value"]
+    roofline = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roofline)
+    assert 0. < roofline["frac"] <= 1.
+    assert abs(roofline["frac"] - roofline["achieved"]/roofline["peak"]) < 1e-12
+
+
+def test_single_gpu_line():
+    line = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--extras",
+                "pedestal", "--cpu-sample-cm", "200"])
+    check(line, 1, 3, 1)
+    assert line["config"]["workload"].startswith("BASELINE config 'target'")
+    baseline = line["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(baseline)
+    assert baseline["cores"] == 1 and baseline["kind"] in ("reference", "port")
+    assert line["pedestal_option"]["value"] > 1.e9
+
+
+def test_two_rank_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                "--backend", "gloo", "--config", "1", "--steps", "2", "--warmup", "1"])
+    check(line, 2, 2, 1)
+    assert "cpu_baseline" not in line           # rank 0 at N = 1 only
+    assert line["config"]["levels_total"] == 2
