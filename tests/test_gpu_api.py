@@ -549,7 +549,9 @@ def test_compat_entry_device_and_cache(tmp_path):
     """)
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra, expect in (({"LBL_DEVICE": "0"}, 0), ({"LOCAL_RANK": "5"}, 5 % 1), ({}, 0)):
+    import torch
+    visible = max(torch.cuda.device_count(), 1)         # counts devices without touching them
+    for extra, expect in (({"LBL_DEVICE": "0"}, 0), ({"LOCAL_RANK": "5"}, 5 % visible), ({}, 0)):
         env = {k: v for k, v in os.environ.items() if k not in ("LBL_DEVICE", "LOCAL_RANK")}
         env.update(extra)
         env.update({"LBL_COMPAT_CACHE": "2", "EXPECT_DEVICE": str(expect), "LBL_TEST_ROOT": root,
