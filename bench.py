@@ -89,6 +89,9 @@ def parse():
     parser.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                         help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo "
                              "only to rehearse the multi-rank flow on fewer GPUs than ranks)")
+    parser.add_argument("--exchange-timeout", type=float, default=180.,
+                        help="N > 1: seconds any collection of spectra, barrier or reduction may "
+                             "take before the rank reports what it was waiting for and exits 3")
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
@@ -545,7 +548,48 @@ def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
     }
 
 
+def device_identity(torch, index):
+    """What tells two GPUs apart: name, UUID and PCI address of HIP device `index` (each only
+    where this torch exposes it)."""
+    out = {"device_index": index}
+    try:
+        props = torch.cuda.get_device_properties(index)
+    except Exception as error:          # diagnostics must not stop the run
+        return dict(out, error=str(error))
+    out["name"] = props.name
+    for key in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id", "gcnArchName",
+                "multi_processor_count"):
+        value = getattr(props, key, None)
+        if value is not None:
+            out[key] = str(value) if key == "uuid" else value
+    out["hip_visible_devices"] = os.environ.get("HIP_VISIBLE_DEVICES")
+    return out
+
+
 def main():
+    """Runs the benchmark; a rank that fails says which rank it is and what it was doing, then
+    leaves with a non-zero code so that the launcher stops the others (a rank blocked in a
+    collective cannot be woken, and a process that holds a GPU is never re-executed)."""
+    rank = os.environ.get("RANK", "0")
+    try:
+        run()
+    except SystemExit:
+        raise
+    except BaseException as error:
+        import traceback
+        from pylbl_amd.distributed import ExchangeTimeout
+        late = isinstance(error, ExchangeTimeout)
+        print(json.dumps({"bench_failed": True, "rank": int(rank),
+                          "world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "kind": type(error).__name__, "message": str(error),
+                          "traceback": traceback.format_exc().splitlines()[-12:]}),
+              file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3 if late else 1)
+
+
+def run():
     args = parse()
     if args.no_extras:
         args.extras = "none"
@@ -569,11 +613,35 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback).")
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
+    identity = dict(device_identity(torch, device_index), rank=rank, local_rank=local_rank,
+                    host=os.uname().nodename, pid=os.getpid())
     if world > 1:
+        from datetime import timedelta
+        os.environ.setdefault("PYLBL_AMD_EXCHANGE_TIMEOUT", str(args.exchange_timeout))
+        limit = timedelta(seconds=max(args.exchange_timeout, 30.))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
+                                    timeout=limit)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
+        # Who is here: every rank's device, before anything is computed.  N ranks must sit on N
+        # different GPUs for the N-GPU figure to mean anything (RCCL refuses two ranks on one
+        # device; gloo does not).
+        everyone = [None]*world
+        dist.all_gather_object(everyone, identity)
+        seen = {}
+        for other in everyone:
+            key = (other.get("host"), other.get("uuid") or other.get("pci_bus_id"),
+                   other.get("device_index"))
+            seen.setdefault(key, []).append(other["rank"])
+        shared = {str(k): v for k, v in seen.items() if len(v) > 1}
+        if shared and args.backend == "nccl":
+            raise RuntimeError(f"ranks share a GPU: {shared}")
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, the "
+                               f"launcher announced {world}")
+    else:
+        everyone, shared = [identity], {}
 
     from pylbl_amd import distributed, synthetic
     from pylbl_amd.engine import Engine
@@ -641,8 +709,7 @@ def main():
         if world > 1 and pending[which] is not None:
             # The exchange that last read this pair of buffers.  (One rank: the engine's own
             # streams order successive writes to a buffer, nothing to wait for.)
-            pending[which].wait()
-            pending[which] = None
+            settle(which)
         if args.host_output:
             for m, formula in enumerate(molecules):
                 engine.compute(handles[formula], atmos.t, atmos.p, vmr[formula], *grid_args,
@@ -651,11 +718,24 @@ def main():
         pending[which] = sharded.run(atmos.t, atmos.p, vmr, dst=0, output=args.output,
                                      async_op=True)
 
+    exchange = {"count": 0, "wait_s": 0., "in_flight_s": 0., "sent": 0, "received": 0}
+
+    def settle(which):
+        """Waits for the exchange that owns buffer pair `which` and books what it moved."""
+        item = pending[which]
+        pending[which] = None
+        begin = time.perf_counter()
+        item.wait(timeout=args.exchange_timeout)
+        exchange["wait_s"] += time.perf_counter() - begin
+        exchange["in_flight_s"] += item.seconds or 0.
+        exchange["count"] += 1
+        exchange["sent"] += item.bytes_sent
+        exchange["received"] += item.bytes_received
+
     def fence():
         for which in (0, 1):
             if pending[which] is not None:
-                pending[which].wait()
-                pending[which] = None
+                settle(which)
         engine.synchronize()
         if world > 1:
             dist.barrier()
@@ -675,6 +755,8 @@ def main():
     engine.set_option("timing", 2)
     engine.timing(reset=True)
     fence()
+    for key in exchange:
+        exchange[key] = 0
     start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -682,6 +764,32 @@ def main():
     elapsed = time.perf_counter() - start
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
+
+    per_rank = None
+    if world > 1 and not args.host_output:
+        # The exchange by itself, once, outside the timed region: kernels first (host waits),
+        # then the collection alone -- what a step would pay if nothing overlapped it.
+        fence()
+        begin = time.perf_counter()
+        alone = sharded.run(atmos.t, atmos.p, vmr, dst=0, output=args.output, async_op=True)
+        engine.synchronize()
+        computed = time.perf_counter()
+        alone.wait(timeout=args.exchange_timeout)
+        finished = time.perf_counter()
+        mine = dict(identity, seconds=elapsed, ms_per_step=elapsed/args.steps*1e3,
+                    evals_per_step=int(evals_per_step_local),
+                    units=len(plan.units[rank]), levels=len(plan.levels_of(rank)),
+                    exchanges=exchange["count"],
+                    bytes_sent_per_step=exchange["sent"]/max(exchange["count"], 1),
+                    bytes_received_per_step=exchange["received"]/max(exchange["count"], 1),
+                    exchange_wait_ms_per_step=exchange["wait_s"]/args.steps*1e3,
+                    exchange_in_flight_ms=exchange["in_flight_s"]/max(exchange["count"], 1)*1e3,
+                    unoverlapped_compute_ms=(computed - begin)*1e3,
+                    unoverlapped_exchange_ms=(finished - computed)*1e3,
+                    accumulate_ms_per_step=kernel_ms[2]/args.steps)
+        per_rank = [None]*world
+        dist.all_gather_object(per_rank, mine)
+        fence()
 
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
                          device="cpu" if (world > 1 and args.backend == "gloo") else "cuda")
@@ -722,6 +830,23 @@ def main():
                                f"{plan.mode} sharded"
                 + (f", one grouped {args.backend} send/recv to rank 0 per step, overlapping the "
                    f"next step" if world > 1 else ""),
+            },
+            "distributed": None if world == 1 else {
+                "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "distinct_devices": len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id"),
+                                          r.get("device_index")) for r in everyone}),
+                "ranks_sharing_a_device": shared,
+                "exchange_timeout_s": args.exchange_timeout,
+                "bytes_to_rank0_per_step": (per_rank or [{}])[0].get("bytes_received_per_step"),
+                "exchange_alone_ms_max": max((r["unoverlapped_exchange_ms"]
+                                              for r in per_rank), default=None)
+                if per_rank else None,
+                "note": "per rank: the device it ran on, its own wall time for the timed steps, "
+                        "bytes it sent/received per step, host time it spent waiting for an "
+                        "exchange inside the timed steps (exchange_wait_ms_per_step; 0 = fully "
+                        "hidden behind the next step's kernels) and one un-overlapped step "
+                        "(kernels, then the collection alone) measured after the timed region",
+                "ranks": per_rank if per_rank else everyone,
             },
             "evals_per_step": evals_per_step,
             "evals_per_s_per_gpu": value/world,

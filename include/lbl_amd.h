@@ -121,6 +121,17 @@ int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t re
  * several streams, so events on this one do not bracket them (use lbl_synchronize / lbl_timing). */
 void *lbl_stream(lbl_engine *engine);
 
+/* Sharing HBM blocks with another HIP user of the same device without stopping the host (the
+ * reference has no analogue: it is serial and host-only; this is what lets the collection of a
+ * multi-GPU call, pylbl_amd/distributed.py, start behind the kernels instead of behind a
+ * lbl_synchronize).  `stream` is a hipStream_t of the caller, NULL for the null stream.
+ *   lbl_order_stream_after_engine: work the caller queues on `stream` from now on runs after
+ *     everything queued on the engine so far (it may read what the engine wrote);
+ *   lbl_order_engine_after_stream: everything the engine queues from now on runs after what
+ *     `stream` holds now (the engine may overwrite what that work read). */
+int lbl_order_stream_after_engine(lbl_engine *engine, void *stream);
+int lbl_order_engine_after_stream(lbl_engine *engine, void *stream);
+
 /* Device memory helpers so that hosts without a HIP binding can keep spectra in HBM. */
 int lbl_device_alloc(lbl_engine *engine, int64_t bytes, void **pointer);
 int lbl_device_free(lbl_engine *engine, void *pointer);

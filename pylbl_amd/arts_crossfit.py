@@ -70,17 +70,32 @@ class CrossSection(object):
         path: Path to the coefficient file.
     """
     def __init__(self, formula, path, device=0, engine=None):
+        """Reads the coefficient file and uploads its bands.
+
+        The reference's constructor only stores its arguments and opens the file on every call
+        (cross_section.py:10-19,29), and Spectroscopy's MoleculeCache lets nothing but the two
+        database errors pass (pyLBL/spectroscopy.py:66-69): a file that cannot be read is
+        therefore reported by the first ``absorption_coefficient`` call, as there.
+        """
         self.formula = formula
         self.path = path
         self.engine = engine if engine is not None else default_engine(device)
-        bands = read_bands(path)
+        self.handle = None
+        self._deferred_error = None
+        try:
+            bands = read_bands(path)
+        except (OSError, KeyError, ValueError, TypeError) as error:
+            self._deferred_error = error
+            self.sizes, self.frequency = [], []
+            return
         self.sizes = [f.size for f, _ in bands]
         self.frequency = [f for f, _ in bands]
         self.handle = self.engine.load_xsec(bands)
 
     def __del__(self):
         try:
-            self.engine.free_xsec(self.handle)
+            if self.handle is not None:
+                self.engine.free_xsec(self.handle)
         except Exception:
             pass
 
@@ -93,6 +108,8 @@ class CrossSection(object):
         """All levels in one call: float64[levels, grid.size] (or fills `out`, a host array
         or DeviceSpectra).  With volume_mixing_ratio the result is n k [m-1], the slot
         Spectroscopy stores (spectroscopy.py:199-203)."""
+        if self._deferred_error is not None:
+            raise self._deferred_error
         grid = grid if isinstance(grid, np.ndarray) and grid.dtype == np.float64 and \
             grid.flags["C_CONTIGUOUS"] else np.ascontiguousarray(grid, dtype=np.float64)
         return self.engine.xsec_compute(
@@ -102,4 +119,6 @@ class CrossSection(object):
     def band_values(self, temperature, pressure):
         """The clipped fit on the bands' own frequency grids (calculate_xsec_fullmodel per
         band, xsec_aux_functions.py:80-121)."""
+        if self._deferred_error is not None:
+            raise self._deferred_error
         return self.engine.xsec_bands(self.handle, self.sizes, temperature, pressure)

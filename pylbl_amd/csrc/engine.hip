@@ -147,6 +147,7 @@ struct Lane
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
     hipEvent_t runs_found = nullptr;
     hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
+    hipEvent_t handed_over = nullptr;   // what a caller's stream waits for (lbl_order_stream_after_engine)
     // The last few writes of device output queued on this lane: where, and an event behind the
     // kernel that wrote.  A call on another lane that touches the same memory waits for it.
     struct Write { const char * begin = nullptr; const char * end = nullptr; hipEvent_t done = nullptr; };
@@ -188,6 +189,7 @@ struct Lane
         HIP_TRY(hipEventCreateWithFlags(&prepared, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&handed_over, hipEventDisableTiming));
         for (auto & w : writes) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
@@ -206,6 +208,7 @@ struct Lane
         if (pedestal_done != nullptr) (void)hipEventDestroy(pedestal_done);
         if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
         if (queued != nullptr) (void)hipEventDestroy(queued);
+        if (handed_over != nullptr) (void)hipEventDestroy(handed_over);
         for (auto & w : writes) { if (w.done != nullptr) (void)hipEventDestroy(w.done); w.done = nullptr; }
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
@@ -329,6 +332,7 @@ struct lbl_engine
     int device = 0;
     hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
     hipStream_t copy_stream = nullptr;  // results on their way to host memory
+    hipEvent_t copies_handed_over = nullptr, taken_over = nullptr;  // lbl_order_*_after_*
     std::string error;
     std::vector<std::unique_ptr<Molecule>> molecules;
     std::vector<std::unique_ptr<ContinuumSet>> continua;
@@ -759,8 +763,11 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         // only its last kernel (pedestal_apply_kernel) touches the output, everything before
         // works in the lane's own buffers.
         const bool add_into_block = (rq.flags & LBL_ACCUMULATE) != 0;
+        // (A molecule without lines has no pedestal pass: its accumulate kernel itself adds
+        // into the block, so such a call must not leave lane 0's ordering.)
+        const bool pedestal_pass = rq.remove_pedestal && n_lines > 0;
         const bool alternate = (rq.flags & LBL_ASYNC) && want_k && rq.derived == nullptr &&
-                               ((rq.remove_pedestal && (!add_into_block || out_device)) ||
+                               ((pedestal_pass && (!add_into_block || out_device)) ||
                                 (small && out_device && !add_into_block));
         Lane & lane = engine->lanes[alternate ? (engine->next_lane++ % kLanes) : 0];
         hipStream_t stream = lane.main;
@@ -1147,6 +1154,8 @@ int lbl_engine_create(int device, lbl_engine ** engine)
         for (int i = 0; i < kAllLanes; ++i) e->lanes[i].create(i == kSlotLane);
         e->stream = e->lanes[0].main;
         HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->copies_handed_over, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->taken_over, hipEventDisableTiming));
         *engine = e.release();
     }
     catch (const HipFailure & f)
@@ -1173,6 +1182,8 @@ int lbl_engine_destroy(lbl_engine * engine)
     engine->grids.clear();
     for (auto & lane : engine->lanes) lane.destroy();
     if (engine->copy_stream != nullptr) (void)hipStreamDestroy(engine->copy_stream);
+    if (engine->copies_handed_over != nullptr) (void)hipEventDestroy(engine->copies_handed_over);
+    if (engine->taken_over != nullptr) (void)hipEventDestroy(engine->taken_over);
     delete engine;
     return LBL_OK;
 }
@@ -1422,6 +1433,54 @@ int lbl_timing(lbl_engine * engine, double ms[8], int64_t launches[8], int32_t r
 void * lbl_stream(lbl_engine * engine)
 {
     return engine != nullptr ? (void *)engine->stream : nullptr;
+}
+
+// The two halves of sharing HBM blocks with another HIP user of the device (e.g. the library
+// that runs the RCCL exchange of pylbl_amd/distributed.py) without stopping the host: each is a
+// handful of event records and stream waits.
+int lbl_order_stream_after_engine(lbl_engine * engine, void * stream)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        hipStream_t theirs = reinterpret_cast<hipStream_t>(stream);
+        // Side streams end in an event their lane's main stream waits for (pedestal_done), so
+        // the main streams and the copy stream stand for everything the engine has queued.
+        for (auto & lane : engine->lanes)
+        {
+            HIP_TRY(hipEventRecord(lane.handed_over, lane.main));
+            HIP_TRY(hipStreamWaitEvent(theirs, lane.handed_over, 0));
+        }
+        HIP_TRY(hipEventRecord(engine->copies_handed_over, engine->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(theirs, engine->copies_handed_over, 0));
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    return LBL_OK;
+}
+
+int lbl_order_engine_after_stream(lbl_engine * engine, void * stream)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        HIP_TRY(hipEventRecord(engine->taken_over, reinterpret_cast<hipStream_t>(stream)));
+        for (auto & lane : engine->lanes)
+        {
+            HIP_TRY(hipStreamWaitEvent(lane.main, engine->taken_over, 0));
+            HIP_TRY(hipStreamWaitEvent(lane.side, engine->taken_over, 0));
+        }
+        HIP_TRY(hipStreamWaitEvent(engine->copy_stream, engine->taken_over, 0));
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    return LBL_OK;
 }
 
 int lbl_device_alloc(lbl_engine * engine, int64_t bytes, void ** pointer)

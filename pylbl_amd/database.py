@@ -18,6 +18,7 @@ it is uploaded to the GPU; it is also what the synthetic generators produce.
 """
 from collections import namedtuple
 from dataclasses import dataclass
+import os
 import sqlite3
 
 import numpy as np
@@ -255,6 +256,78 @@ class MemoryDatabase(object):
             names=list(LINE_COLUMNS) + ["local_iso_id"])
         tips = TotalPartitionFunction(name, table.tips_temperature, table.tips_data)
         return GasData(table.formula, list(table.mass), transitions, tips)
+
+
+def _column(transitions, name, dtype):
+    """One field of the reference's transition rows (a list of ORM objects,
+    pyLBL/database.py:446-459) or of a record array, as a contiguous array."""
+    if hasattr(transitions, "dtype") and transitions.dtype.names:
+        return np.ascontiguousarray(transitions[name], dtype=dtype)
+    return np.fromiter((getattr(row, name) for row in transitions), dtype=dtype,
+                       count=len(transitions))
+
+
+def table_from_gas(lines_database, name):
+    """LineTable assembled from the two query helpers of the reference's Database object,
+    ``.gas(name)`` (pyLBL/database.py:350-367) and ``.tips(name)`` (:369-395), for databases
+    that are not a file this process can open.
+
+    ``.gas()`` hands out the masses in isotopologue-row order without their ``isoid``
+    column, whereas the reference's C reader files them under ``isoid`` (0 -> 10,
+    spectral_database.c:113-129).  HITRAN numbers a molecule's isotopologues 1, 2, ... 9, 0,
+    11, ... in the order it lists them, which is the order ``Database.create`` inserts them
+    in (pyLBL/database.py:58-77), so row r is taken as local id r + 1.
+    """
+    # Partition sums before anything else, as absorption.c:50-64 looks things up: a molecule
+    # without them yields zeros whatever else it lacks (TipsDataNotFoundError here).
+    temperature, data = lines_database.tips(name)
+    formula, mass, transitions, _ = lines_database.gas(name)
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim != 2:
+        raise ValueError("tips data is not rectangular.")       # spectral_database.c:85-90
+    n = len(transitions)
+    if n == 0:
+        raise TransitionsNotFoundError(f"transitions not found for molecule {name}.")
+    columns = {x: _column(transitions, x, np.float64) for x in LINE_COLUMNS}
+    try:
+        molecule_id = int(transitions[0].molecule_id)
+    except (AttributeError, TypeError, ValueError, IndexError):
+        molecule_id = 0
+    return LineTable(
+        formula=formula, molecule_id=molecule_id,
+        local_iso_id=_column(transitions, "local_iso_id", np.int64).astype(np.int32),
+        isoid=np.arange(1, len(mass) + 1, dtype=np.int64),
+        mass=np.asarray(mass, dtype=np.float64),
+        tips_temperature=np.ascontiguousarray(temperature, dtype=np.float64),
+        tips_data=np.ascontiguousarray(data), **columns)
+
+
+def line_table_of(lines_database, name):
+    """Everything the lines engine needs for one molecule, from whichever database object the
+    caller holds -- the reference hands its backends ``pyLBL.database.Database``
+    (pyLBL/spectroscopy.py:54), which has ``.path``, ``.gas()``, ``.tips()``,
+    ``.molecules()`` and ``.arts_crossfit()`` but no ``line_table``:
+
+    1. an object with ``line_table(name)`` (this package's Database / MemoryDatabase);
+    2. an object whose ``.path`` names a readable SQLite file (pyLBL/database.py:146): the
+       file is read with the reference C engine's own four SELECTs, so rows, masses by
+       ``isoid`` and TIPS rows are exactly what ``absorption()`` would see;
+    3. an object with ``.gas(name)`` / ``.tips(name)`` only: ``table_from_gas``.
+
+    Raises whatever the source raises for a molecule it does not know (this package's
+    errors, or the reference's own classes of the same names from routes 1 and 3).
+    """
+    reader = getattr(lines_database, "line_table", None)
+    if callable(reader):
+        return reader(name)
+    path = getattr(lines_database, "path", None)
+    if isinstance(path, (str, os.PathLike)) and os.path.isfile(path):
+        return Database(path).line_table(name)
+    if callable(getattr(lines_database, "gas", None)):
+        return table_from_gas(lines_database, name)
+    raise TypeError(
+        f"{type(lines_database).__name__} is not a line database: it needs line_table(name), "
+        "a .path to an SQLite file in pyLBL's schema, or gas(name)/tips(name).")
 
 
 # Exact DDL of the reference's schema (pyLBL/database.py:418-486 as emitted by

@@ -134,33 +134,108 @@ def gather_levels(local, n_levels, dst=0, group=None):
         dist.all_gather(pieces, padded, group=group)
     else:
         pieces = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-        dist.gather(padded, pieces, dst=dst, group=group)
+        dist.gather(padded, pieces, dst=_global_rank(group, dst), group=group)
         if rank != dst:
             return None
     return torch.cat([pieces[r][:sizes[r]] for r in range(world)], dim=0)
 
 
+class ExchangeTimeout(RuntimeError):
+    """An exchange did not complete in time: names this rank and the peers it was waiting for.
+    A hung collective cannot be cancelled; callers print what they know and leave the process
+    (bench.py exits non-zero with ``os._exit``; never re-exec a process that holds a GPU)."""
+
+
+def exchange_timeout():
+    """Seconds a Pending waits by default: $PYLBL_AMD_EXCHANGE_TIMEOUT, else 300."""
+    import os
+    try:
+        return float(os.environ.get("PYLBL_AMD_EXCHANGE_TIMEOUT", "300"))
+    except ValueError:
+        return 300.
+
+
+def _global_rank(group, rank):
+    """torch's point-to-point and rooted collectives address *global* ranks; inside a
+    sub-group the partition's ranks are group-local."""
+    import torch.distributed as dist
+    if group is None:
+        return rank
+    return dist.get_global_rank(group, rank)
+
+
 class Pending(object):
-    """An exchange in flight: wait() returns what run() would have returned."""
-    def __init__(self, requests, finish, on_device, flush=None):
-        self.requests, self.finish, self.on_device = requests, finish, on_device
+    """An exchange in flight: wait() returns what run() would have returned.
+
+    Attributes:
+        seconds: after wait(): host seconds from the call that started the exchange until its
+                 results were usable (transfer + whatever it overlapped).
+        bytes_sent, bytes_received: what this rank moves in this exchange.
+    """
+    def __init__(self, requests, finish, device=None, flush=None, describe="", rank=0,
+                 peers=(), bytes_sent=0, bytes_received=0):
+        import time
+        self.requests, self.finish, self.device = requests, finish, device
         self.flush = flush
+        self.describe, self.rank, self.peers = describe, rank, tuple(peers)
+        self.bytes_sent, self.bytes_received = int(bytes_sent), int(bytes_received)
+        self.started = time.perf_counter()
+        self.seconds = None
         self.result = None
         self.done = False
 
-    def wait(self):
-        if not self.done:
-            if self.flush is not None:
-                self.flush()
+    def _late(self, timeout):
+        return ExchangeTimeout(
+            f"rank {self.rank}: {self.describe or 'exchange'} with rank(s) "
+            f"{list(self.peers)} not complete after {timeout:g} s "
+            f"({self.bytes_sent} B to send, {self.bytes_received} B to receive)")
+
+    def wait(self, timeout=None):
+        """Blocks until the exchange has finished and its result may be read.
+
+        Args:
+            timeout: seconds (default ``exchange_timeout()``); ExchangeTimeout when exceeded.
+        """
+        import time
+        if self.done:
+            return self.result
+        timeout = exchange_timeout() if timeout is None else float(timeout)
+        deadline = time.perf_counter() + timeout
+        if self.flush is not None:
+            self.flush()
+        if self.device is None:
+            # Host tensors (gloo): the requests complete on the host.
+            # (gloo's point-to-point work objects complete inside wait() only: no polling.)
+            from datetime import timedelta
             for request in self.requests:
-                request.wait()
-            if self.on_device:
-                import torch
-                # nccl work objects only order the *current torch stream* behind the transfer;
-                # the engine computes on its own streams, so settle the device side here.
-                torch.cuda.current_stream().synchronize()
-            self.result = self.finish()
-            self.done = True
+                left = deadline - time.perf_counter()
+                try:
+                    done = left > 0. and request.wait(timeout=timedelta(seconds=left))
+                except RuntimeError as error:
+                    raise self._late(timeout) from error
+                if done is False:
+                    raise self._late(timeout)
+        elif self.requests:
+            import torch
+            # An nccl work object only orders the *current torch stream of its device* behind
+            # the transfer: name the device (the caller's current device may be another one)
+            # and settle that stream with an event that can be polled against the deadline.
+            stream = torch.cuda.current_stream(self.device)
+            with torch.cuda.device(self.device):
+                for request in self.requests:
+                    request.wait()
+                marker = torch.cuda.Event()
+                marker.record(stream)
+            spins = 0
+            while not marker.query():
+                spins += 1
+                if spins > 2000:
+                    if time.perf_counter() > deadline:
+                        raise self._late(timeout)
+                    time.sleep(1e-4)
+        self.result = self.finish()
+        self.seconds = time.perf_counter() - self.started
+        self.done = True
         return self.result
 
 
@@ -178,9 +253,14 @@ class ShardedLines(object):
         device: torch device of the per-rank blocks ("cpu" in the gloo tests).
         flush: Callable that returns once everything `compute` queued has finished (the
                engine's synchronize); None if `compute` is synchronous.
+        order: Callable that orders the exchange library's stream on `device` behind everything
+               `compute` has queued, without stopping the host (for_engine: HIP events between
+               the engine's streams and torch's); None: `flush` is used instead.
+        zero: Callable (tensor) that zero-fills a block in the order `compute` works in
+              (for_engine: the engine's own fill); None: torch fills and the host waits.
     """
     def __init__(self, compute, molecules, n, weights=None, group=None, device="cpu",
-                 flush=None):
+                 flush=None, order=None, zero=None):
         self.compute = compute
         self.molecules = list(molecules)
         self.n = int(n)
@@ -188,8 +268,11 @@ class ShardedLines(object):
         self.group = group
         self.device = device
         self.flush = flush
+        self.order = order
+        self.zero = zero
         self._buffers = {}
         self._turn = 0
+        self.last_exchange = None       # the Pending of the latest call with world > 1
 
     @classmethod
     def for_engine(cls, engine, handles, grid_args, remove_pedestal=False, scale_density=False,
@@ -215,8 +298,17 @@ class ShardedLines(object):
                                remove_pedestal=remove_pedestal, scale_density=scale_density,
                                range_policy=range_policy, out=Slot(out), accumulate=accumulate,
                                asynchronous=True)
-        return cls(compute, list(handles), n, weights=weights, group=group,
-                   device=torch.device("cuda", engine.device), flush=engine.synchronize)
+        device = torch.device("cuda", engine.device)
+
+        def order():
+            # torch's current stream of the engine's device waits (on the device) for the
+            # engine's streams; the exchange torch launches next is ordered behind that stream.
+            engine.order_stream_after(torch.cuda.current_stream(device).cuda_stream)
+
+        def zero(tensor):
+            engine.fill_zero(Slot(tensor), asynchronous=True)
+        return cls(compute, list(handles), n, weights=weights, group=group, device=device,
+                   flush=engine.synchronize, order=order, zero=zero)
 
     # -- buffers -----------------------------------------------------------------------------
     def _buffer(self, name, shape, zero=False):
@@ -233,8 +325,13 @@ class ShardedLines(object):
         return tensor
 
     def _zero(self, tensor):
-        """torch queues the fill on its own stream; the engine computes on others, so the fill
-        has to have happened before `compute` is handed the block."""
+        """With the engine's own fill the zeroes are ordered like a compute call.  Otherwise
+        torch queues the fill on its own stream; the engine computes on others, so the fill has
+        to have happened before `compute` is handed the block."""
+        if self.zero is not None and tensor.is_cuda and tensor.is_contiguous() \
+                and tensor.dim() == 2:
+            self.zero(tensor)
+            return
         tensor.zero_()
         if tensor.is_cuda:
             import torch
@@ -310,47 +407,67 @@ class ShardedLines(object):
             else:
                 result = {f: blocks[m] for m, f in enumerate(self.molecules)}
             if async_op:
-                return Pending([], lambda: result, False, flush=self.flush)
+                return Pending([], lambda: result, flush=self.flush)
             if self.flush is not None:
                 self.flush()
             return result
-        if self.flush is not None:
+        if on_device and not through_host and self.order is not None:
+            # RCCL: the exchange is queued behind the kernels on the device; the host goes on
+            # (to the next call's kernels: compute k+1 runs beside exchange k).
+            self.order()
+        elif self.flush is not None:
             self.flush()
 
         if through_host:
             blocks = {key: value.cpu() for key, value in blocks.items()}
         where = "cpu" if (through_host or not on_device) else self.device
+        wait_on = None if where == "cpu" else self.device
+        sizes = {key: value.numel()*8 for key, value in blocks.items()}
 
         # 3. exchange
         receivers = range(world) if dst is None else (dst,)
         i_receive = rank in receivers
         if output == "total" and plan.mode == "units":
             # The molecules of one level sit on several ranks: a real sum over ranks.
-            partial = torch.zeros((n_levels, n), dtype=torch.float64, device=where)
+            partial = self._buffer("reduce", (n_levels, n)) if where != "cpu" else \
+                torch.empty((n_levels, n), dtype=torch.float64)
+            partial.zero_()
             for i, level in enumerate(my_levels):
                 partial[level] = blocks[None][i]
             if dst is None:
                 work = dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group,
                                        async_op=True)
             else:
-                work = dist.reduce(partial, dst=dst, op=dist.ReduceOp.SUM, group=self.group,
-                                   async_op=True)
+                work = dist.reduce(partial, dst=_global_rank(self.group, dst),
+                                   op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             finish = (lambda: partial) if i_receive else (lambda: None)
-            pending = Pending([work], finish, where != "cpu")
+            pending = Pending([work], finish, device=wait_on, rank=rank,
+                              describe="sum over ranks of the per-level totals "
+                                       f"({'all_reduce' if dst is None else 'reduce'})",
+                              peers=[r for r in range(world) if r != rank],
+                              bytes_sent=partial.numel()*8,
+                              bytes_received=partial.numel()*8 if i_receive else 0)
+            self.last_exchange = pending
             return pending if async_op else pending.wait()
 
         # Grouped point-to-point gather: every block goes straight into its final place.
+        # The collected array is kept between calls like the per-rank blocks (two of each, used
+        # in turn): "gas" output of BASELINE config 5 is 164 GB on the receiving rank.
+        def collected(shape):
+            if not i_receive:
+                return None
+            if where == "cpu":
+                return torch.empty(shape, dtype=torch.float64)
+            return self._buffer("final", shape)
         if output == "total":
-            final = torch.empty((n_levels, n), dtype=torch.float64, device=where) \
-                if i_receive else None
+            final = collected((n_levels, n))
             pieces = lambda r: [(None, plan.levels_of(r))]                      # noqa: E731
             place = lambda key, levels: final[levels[0]:levels[-1] + 1]          # noqa: E731
         else:
-            final = torch.empty((m_count, n_levels, n), dtype=torch.float64, device=where) \
-                if i_receive else None
+            final = collected((m_count, n_levels, n))
             pieces = lambda r: sorted(plan.by_molecule(r).items())              # noqa: E731
             place = lambda key, levels: final[key, levels[0]:levels[-1] + 1]     # noqa: E731
-        ops = []
+        ops, peers, sent, received = [], set(), 0, 0
         for receiver in receivers:
             if receiver == rank:
                 for sender in range(world):
@@ -360,12 +477,18 @@ class ShardedLines(object):
                         if sender == rank:
                             place(key, levels).copy_(blocks[key])
                         else:
-                            ops.append(dist.P2POp(dist.irecv, place(key, levels), sender,
-                                                  self.group))
+                            target = place(key, levels)
+                            ops.append(dist.P2POp(dist.irecv, target,
+                                                  _global_rank(self.group, sender), self.group))
+                            peers.add(sender)
+                            received += target.numel()*8
             else:
                 for key, levels in pieces(rank):
                     if levels:
-                        ops.append(dist.P2POp(dist.isend, blocks[key], receiver, self.group))
+                        ops.append(dist.P2POp(dist.isend, blocks[key],
+                                              _global_rank(self.group, receiver), self.group))
+                        peers.add(receiver)
+                        sent += sizes[key]
         requests = dist.batch_isend_irecv(ops) if ops else []
 
         def finish():
@@ -374,22 +497,28 @@ class ShardedLines(object):
             if output == "total":
                 return final
             return {f: final[m] for m, f in enumerate(self.molecules)}
-        pending = Pending(requests, finish, where != "cpu")
+        pending = Pending(requests, finish, device=wait_on, rank=rank,
+                          describe=f"grouped send/recv of the {output!r} blocks to "
+                                   f"{'every rank' if dst is None else f'rank {dst}'}",
+                          peers=sorted(peers), bytes_sent=sent, bytes_received=received)
+        self.last_exchange = pending
         return pending if async_op else pending.wait()
 
 
-def gather_arrays(local, n_levels, dst=0, group=None):
+def gather_arrays(local, n_levels, dst=0, group=None, device=None):
     """Collects host arrays [levels_local, ...] of a level-sharded call (``level_shard``) on
     rank `dst` (every rank if dst is None): what ``Spectroscopy(group=...)`` uses for its
     result arrays, which live in host memory by the reference's contract.  With the nccl
-    backend the blocks are staged through HBM, with gloo they travel as they are."""
+    backend the blocks are staged through the HBM of GPU `device` (the engine's; torch's current
+    device if None -- which is every rank's GPU 0 unless the caller set it), with gloo they
+    travel as they are."""
     import torch
-    import torch.distributed as dist
     rank, world, backend = _group_info(group)
     if world == 1:
         return local
     tensor = torch.from_numpy(np.ascontiguousarray(local))
     if backend == "nccl":
-        tensor = tensor.cuda()
+        tensor = tensor.to(torch.device("cuda", torch.cuda.current_device() if device is None
+                                        else int(device)))
     out = gather_levels(tensor, n_levels, dst=dst, group=group)
     return None if out is None else out.cpu().numpy()

@@ -25,7 +25,8 @@ RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
 EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
     "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
-    "lbl_stream", "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
+    "lbl_stream", "lbl_order_stream_after_engine", "lbl_order_engine_after_stream",
+    "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
     "lbl_line_scalars", "lbl_absorption", "absorption", "lbl_compat_state", "lbl_fill_zero",
     "lbl_version",
@@ -107,6 +108,8 @@ def library():
     lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
     lib.lbl_stream.argtypes = [c_void_p]
     lib.lbl_stream.restype = c_void_p
+    lib.lbl_order_stream_after_engine.argtypes = [c_void_p, c_void_p]
+    lib.lbl_order_engine_after_stream.argtypes = [c_void_p, c_void_p]
     lib.lbl_device_alloc.argtypes = [c_void_p, c_int64, POINTER(c_void_p)]
     lib.lbl_device_free.argtypes = [c_void_p, c_void_p]
     lib.lbl_copy_to_host.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
@@ -540,6 +543,15 @@ class Engine(object):
     @property
     def stream(self):
         return self.lib.lbl_stream(self.handle)
+
+    def order_stream_after(self, stream):
+        """Work queued on `stream` (a raw hipStream_t, e.g. torch.cuda.Stream.cuda_stream) from
+        now on runs after everything queued on the engine so far; the host does not wait."""
+        self._check(self.lib.lbl_order_stream_after_engine(self.handle, c_void_p(stream or None)))
+
+    def order_after_stream(self, stream):
+        """Everything the engine queues from now on runs after what `stream` holds now."""
+        self._check(self.lib.lbl_order_engine_after_stream(self.handle, c_void_p(stream or None)))
 
 
 _default_engines = {}

@@ -10,9 +10,9 @@ import warnings
 
 import numpy as np
 
+from . import errors
+from .database import LineTable, line_table_of
 from .engine import default_engine
-from .errors import AliasNotFoundError, IsotopologuesNotFoundError, TipsDataNotFoundError, \
-                    TransitionsNotFoundError
 from .synthetic import grid_arguments
 
 
@@ -30,8 +30,10 @@ class Gas(object):
         """Reads the molecule's transitions, masses and partition sums once and uploads them.
 
         Args:
-            lines_database: anything with ``.path`` and ``.line_table(formula)`` (Database,
-                            MemoryDatabase), or a pylbl_amd.database.LineTable itself.
+            lines_database: what the reference passes its back ends (pyLBL/spectroscopy.py:54):
+                            a pyLBL.database.Database -- read through its ``.path``, else
+                            through ``.gas()``/``.tips()`` (database.line_table_of) --, this
+                            package's Database / MemoryDatabase, or a LineTable itself.
             formula: the molecule, e.g. "CO2" (any alias the database knows).
             device: GPU index.
             engine: an Engine to share; by default the process-wide one of `device`.
@@ -40,23 +42,26 @@ class Gas(object):
         self.engine = engine if engine is not None else default_engine(device)
         self.molecule = None
         self._deferred_error = None
-        if hasattr(lines_database, "line_table"):
-            self.database = lines_database.path
-            try:
-                table = lines_database.line_table(formula)
-            except AliasNotFoundError:
-                # Reference: the constructor succeeds, the C call returns 1
-                # (spectral_database.c:152-156) -> ValueError at compute time.
-                self._deferred_error = ValueError("Error inside c functions.")
-                table = None
-            except (TipsDataNotFoundError, TransitionsNotFoundError):
-                table = None    # absorption.c:53-59: rc 0 and a zero spectrum
-            except IsotopologuesNotFoundError:
-                self._deferred_error = ValueError("Error inside c functions.")
-                table = None
-        else:
+        if isinstance(lines_database, LineTable):
             self.database = None
             table = lines_database
+        else:
+            self.database = getattr(lines_database, "path", None)
+            try:
+                table = line_table_of(lines_database, formula)
+            except BaseException as error:
+                # This package's classes, or the reference's own when `lines_database` is a
+                # pyLBL.database.Database that had to be read through .gas()/.tips().
+                condition = errors.kind(error)
+                if condition in ("AliasNotFoundError", "IsotopologuesNotFoundError"):
+                    # Reference: the constructor succeeds, the C call returns 1
+                    # (spectral_database.c:126-129,152-156) -> ValueError at compute time.
+                    self._deferred_error = ValueError("Error inside c functions.")
+                elif condition in ("TipsDataNotFoundError", "TransitionsNotFoundError"):
+                    pass        # absorption.c:53-59: rc 0 and a zero spectrum
+                else:
+                    raise
+                table = None
         self.num_lines = table.num_lines if table is not None else 0
         self._first_nu = float(table.nu[0]) if self.num_lines else None
         if table is not None:

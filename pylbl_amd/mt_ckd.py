@@ -106,18 +106,20 @@ def resident_grid(engine, grid):
     freed here."""
     cache = engine.__dict__.setdefault("_resident_grids", [])
     found = None
+    # Entries leave the list by identity: comparing two of them compares their weak references,
+    # i.e. the arrays behind them, element by element.
     for entry in list(cache):
         target = entry[0]()
         if target is None:
             engine.free_grid(entry[1])
-            cache.remove(entry)
+            cache[:] = [other for other in cache if other is not entry]
         elif target is grid:
             found = entry
     fingerprint = _grid_fingerprint(grid)
     if found is not None and found[2] != fingerprint:
         engine.synchronize()        # queued kernels may still read the old copy
         engine.free_grid(found[1])
-        cache.remove(found)
+        cache[:] = [other for other in cache if other is not found]
         found = None
     if found is None:
         handle = engine.load_grid(grid)

@@ -17,9 +17,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from .errors import AliasNotFoundError, CrossSectionNotFoundError, \
-                    IsotopologuesNotFoundError, TipsDataNotFoundError, TransitionsNotFoundError
-
+from . import errors
 from .plugins import continua, cross_sections, molecular_lines
 from .synthetic import grid_arguments
 
@@ -90,10 +88,14 @@ class MoleculeCache(object):
     uploads the molecule's line table and continuum coefficients to HBM once."""
     def __init__(self, name, lines_database, lines_engine, continua_engine,
                  cross_sections_engine, device):
+        # `lines_database` may be the reference's own Database object, whose error classes are
+        # not this package's: the conditions are told apart by name (errors.kind).
         try:
             self.gas = lines_engine(lines_database, name, device=device)
-        except (AliasNotFoundError, IsotopologuesNotFoundError,
-                TipsDataNotFoundError, TransitionsNotFoundError):
+        except BaseException as error:
+            if errors.kind(error) not in ("AliasNotFoundError", "IsotopologuesNotFoundError",
+                                          "TipsDataNotFoundError", "TransitionsNotFoundError"):
+                raise
             self.gas = None
         # Water vapour has two continua, every other gas at most one (spectroscopy.py:58-65).
         names = [name + "Foreign", name + "Self"] if name == "H2O" else [name]
@@ -108,7 +110,9 @@ class MoleculeCache(object):
             try:
                 self.cross_section = cross_sections_engine(
                     name, lines_database.arts_crossfit(name), device=device)
-            except (AliasNotFoundError, CrossSectionNotFoundError):
+            except BaseException as error:
+                if errors.kind(error) not in ("AliasNotFoundError", "CrossSectionNotFoundError"):
+                    raise
                 self.cross_section = None
 
 
@@ -248,7 +252,8 @@ class Spectroscopy(object):
                 temperature[mine], pressure[mine], {k: v[mine] for k, v in mole_fractions.items()},
                 mode, remove_pedestal, range_policy)
             flat = {name: distributed.gather_arrays(values, temperature.size, self.gather_to,
-                                                    group) for name, values in local.items()}
+                                                    group, device=self.device)
+                    for name, values in local.items()}
             if any(values is None for values in flat.values()):
                 return None
         tail = [len(MECHANISMS), columns] if mode == "all" else [columns]

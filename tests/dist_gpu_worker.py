@@ -1,6 +1,7 @@
-"""One rank of tests/test_gpu_distributed.py::test_two_ranks_share_one_gpu: started as a fresh
-interpreter (env RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), every rank on GPU 0, gloo for
-the exchange (RCCL cannot put two ranks on one device).  Prints "rank R ok" or raises."""
+"""One rank of tests/test_gpu_distributed.py: started as a fresh interpreter (env RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT); DIST_BACKEND=gloo: every rank on GPU 0 (RCCL cannot put
+two ranks on one device), DIST_BACKEND=nccl: one GPU per rank, RCCL carries the exchange.
+Prints "rank R ok" or raises."""
 import os
 import sys
 
@@ -22,11 +23,15 @@ def main():
     backend = os.environ.get("DIST_BACKEND", "gloo")
     device = rank if backend == "nccl" else 0
     torch.cuda.set_device(device)
+    from datetime import timedelta
+    os.environ.setdefault("PYLBL_AMD_EXCHANGE_TIMEOUT", "120")
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", device))
+                                device_id=torch.device("cuda", device),
+                                timeout=timedelta(seconds=180))
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=timedelta(seconds=180))
     formulas = ("H2O", "CO2", "O3")
     tables = {f: synthetic.line_table(f, 600., 700., num_lines=500 + 300*i, seed=31 + i)
               for i, f in enumerate(formulas)}

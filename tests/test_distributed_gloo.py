@@ -62,22 +62,34 @@ def _free_port():
 
 
 FORMULAS = ("H2O", "CO2", "O3")
+EIGHT = ("H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2")
 GRID = (1, 41, 10)
 
 
-def _tables():
+def _tables(formulas=FORMULAS):
     return {f: synthetic.line_table(f, 1., 80., num_lines=60 + 40*i, tips_range=(150, 400))
-            for i, f in enumerate(FORMULAS)}
+            for i, f in enumerate(formulas)}
 
 
-def _worker(rank, world, port, n_levels, dst, output, queue):
+def _worker(rank, world, port, n_levels, dst, output, queue, FORMULAS=FORMULAS, members=None):
+    """members: global ranks of a sub-group that does the work (the others only join the
+    rendezvous); `dst` is then a rank *within that group*."""
     import torch
     import torch.distributed as dist
     from oracle import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tables = _tables()
+    group = None
+    if members is not None:
+        group = dist.new_group(list(members))
+        if rank not in members:
+            queue.put((rank, True, 0))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+    group_rank = dist.get_rank(group)
+    tables = _tables(FORMULAS)
     atmos = synthetic.standard_atmosphere(max(n_levels, 2))
     t, p = atmos.t[:n_levels], atmos.p[:n_levels]
     vmr = {f: atmos.vmr[f][:n_levels] for f in FORMULAS}
@@ -94,7 +106,7 @@ def _worker(rank, world, port, n_levels, dst, output, queue):
         else:
             out.copy_(torch.from_numpy(rows))
 
-    sharded = distributed.ShardedLines(compute, FORMULAS, (vn - v0)*npv,
+    sharded = distributed.ShardedLines(compute, FORMULAS, (vn - v0)*npv, group=group,
                                        weights=[tables[f].num_lines for f in FORMULAS])
     ok = True
     for async_op in (False, True):
@@ -104,9 +116,15 @@ def _worker(rank, world, port, n_levels, dst, output, queue):
         expect = {f: np.asarray([oracle.absorption_port(tables[f], t[i], p[i], vmr[f][i],
                                                         v0, vn, npv)[0] for i in range(n_levels)])
                   for f in FORMULAS}
-        receives = dst is None or rank == dst
+        receives = dst is None or group_rank == dst
+        if world > 1 and (members is None or len(members) > 1):
+            exchange = sharded.last_exchange
+            ok = ok and exchange is not None and exchange.done and exchange.seconds >= 0. \
+                and group_rank not in exchange.peers
+            if dst is not None:
+                ok = ok and (exchange.bytes_received == 0 or receives)
         if output == "total":
-            total = expect["H2O"] + expect["CO2"] + expect["O3"]
+            total = sum(expect[f] for f in FORMULAS)
             ok = ok and ((out is None) if not receives else
                          bool(np.allclose(out.numpy(), total, rtol=1e-14, atol=0.)))
         else:
@@ -128,7 +146,16 @@ def test_ranks_shard_units_and_collect(world, n_levels, dst, output):
     context = mp.get_context("spawn")
     queue = context.Queue()
     port = _free_port()
-    procs = [context.Process(target=_worker, args=(r, world, port, n_levels, dst, output, queue))
+    _run_ranks(world, n_levels, dst, output)
+
+
+def _run_ranks(world, n_levels, dst, output, formulas=FORMULAS, members=None):
+    import torch.multiprocessing as mp
+    context = mp.get_context("spawn")
+    queue = context.Queue()
+    port = _free_port()
+    procs = [context.Process(target=_worker, args=(r, world, port, n_levels, dst, output, queue,
+                                                   formulas, members))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -137,4 +164,66 @@ def test_ranks_shard_units_and_collect(world, n_levels, dst, output):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[:2] for r in results) == [(r, True) for r in range(world)]
-    assert sum(r[2] for r in results) == 2*n_levels*len(FORMULAS)
+    assert sum(r[2] for r in results) == 2*n_levels*len(formulas)
+
+
+def test_config2_units_over_eight_ranks_total_on_every_rank():
+    """BASELINE configs[2] on an 8-GPU node, rehearsed on the CPU: one level x eight molecules is
+    cut into (level, molecule) units, the molecules of the one level sit on several ranks, so
+    the total over gases needs the one real exchange step of the path (all_reduce, dst=None)."""
+    plan = distributed.partition(1, [tables.num_lines for tables in _tables(EIGHT).values()], 8)
+    assert plan.mode == "units" and sum(1 for r in range(8) if plan.units[r]) >= 4
+    _run_ranks(8, 1, None, "total", formulas=EIGHT)
+
+
+@pytest.mark.parametrize("n_levels,dst,output", [(3, 0, "gas"), (1, 1, "total")])
+def test_sub_group_addresses_its_ranks_by_global_rank(n_levels, dst, output):
+    """Ranks 1 and 2 of a three-rank job form the group that computes: `dst` and the senders are
+    ranks within the group, torch's send/recv/reduce want global ranks."""
+    _run_ranks(3, n_levels, dst, output, members=(1, 2))
+
+
+def _late_worker(rank, port, queue):
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+
+    def compute(formula, temperature, pressure, x, out, accumulate):
+        out.fill_(1.)
+    sharded = distributed.ShardedLines(compute, ("CO2",), 64)
+    t = np.asarray([250., 260.])
+    if rank == 1:
+        time.sleep(4.)                       # the peer that is not there in time
+    started = time.perf_counter()
+    try:
+        pending = sharded.run(t, t*100., {"CO2": t*1e-6}, dst=0, async_op=True)
+        pending.wait(timeout=1.0 if rank == 0 else 30.)
+        outcome = "completed"
+    except distributed.ExchangeTimeout as error:
+        outcome = str(error)
+    except RuntimeError as error:           # rank 1: its peer has left meanwhile
+        outcome = f"peer gone: {error}"
+    queue.put((rank, outcome, time.perf_counter() - started))
+    queue.close()
+    queue.join_thread()
+    # A timed-out exchange cannot be cancelled: the process leaves (bench.py: os._exit).
+    os._exit(0)
+
+
+def test_exchange_timeout_names_the_rank_and_its_peers():
+    import torch.multiprocessing as mp
+    context = mp.get_context("spawn")
+    queue = context.Queue()
+    port = _free_port()
+    procs = [context.Process(target=_late_worker, args=(r, port, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (queue.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+    message, seconds = results[0]
+    assert "rank 0" in message and "[1]" in message and "not complete after 1 s" in message
+    assert "B to receive" in message and seconds < 3.5

@@ -499,6 +499,30 @@ def test_asynchronous_pedestal_calls_into_one_buffer_are_ordered():
     e.close()
 
 
+def test_molecule_without_lines_adds_nothing_and_stays_ordered():
+    """A line table without rows (lbl_molecule_load accepts it) in the path that sums gases on
+    the device: asynchronous, pedestal removed, adding into the block another lane is still
+    writing.  It has no pedestal pass, so its accumulate kernel does the read-modify-write
+    itself and must run behind the block's previous writer (it used to rotate to a lane of its
+    own and could write back a stale block)."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    full = synthetic.line_table("H2O", 1., 400., num_lines=30000, seed=71, tips_range=(150, 400))
+    a = e.load(full)
+    empty = e.load(full.subset(np.zeros(full.num_lines, dtype=bool)))
+    v0, vn, npv = 1, 361, 500
+    expect = e.compute(a, 250., 3e4, 5e-3, v0, vn, npv, remove_pedestal=True, scale_density=True)
+    out = DeviceSpectra(e, 1, (vn - v0)*npv)
+    for _ in range(4):
+        e.compute(a, 250., 3e4, 5e-3, v0, vn, npv, remove_pedestal=True, out=out,
+                  scale_density=True, asynchronous=True)                     # writes, on a lane
+        e.compute(empty, 250., 3e4, 1e-3, v0, vn, npv, remove_pedestal=True, out=out,
+                  scale_density=True, accumulate=True, asynchronous=True)    # adds zero
+        assert np.array_equal(out.to_host(), expect)
+    out.free()
+    e.close()
+
+
 def test_compat_entry_device_and_cache(tmp_path):
     """The same-signature entry picks its GPU from LBL_DEVICE / the launcher's local rank,
     re-reads a database file that changed under the same path (the reference re-reads it on

@@ -60,3 +60,18 @@ def test_two_rank_line():
     check(line, 2, 2, 1)
     assert "cpu_baseline" not in line           # rank 0 at N = 1 only
     assert line["config"]["levels_total"] == 2
+    # What makes the first RCCL run on the driver's node diagnosable: who ran where, each rank's
+    # own time, what the collection moved and what it cost.
+    report = line["distributed"]
+    assert report["world_size"] == 2 and report["backend"] == "gloo"
+    assert [r["rank"] for r in report["ranks"]] == [0, 1]
+    assert report["distinct_devices"] == 1 and report["ranks_sharing_a_device"]   # both on GPU 0
+    n = 500000
+    for r in report["ranks"]:
+        assert {"device_index", "name", "ms_per_step", "evals_per_step", "bytes_sent_per_step",
+                "bytes_received_per_step", "exchange_wait_ms_per_step",
+                "unoverlapped_exchange_ms"} <= set(r)
+        assert r["ms_per_step"] > 0. and r["exchanges"] >= 2
+    assert report["ranks"][1]["bytes_sent_per_step"] == 2*n*8          # H2O + CO2 of its level
+    assert report["ranks"][0]["bytes_received_per_step"] == 2*n*8
+    assert report["bytes_to_rank0_per_step"] == 2*n*8
