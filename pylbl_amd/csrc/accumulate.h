@@ -174,15 +174,17 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 // Per row the decisions are wave-uniform: skip (outside the window), Lorentz (whole row in
 // the far wing), or core.  In a core row every lane applies the reference's chain on
 // xi = (v-nu')*repwid (voigt.c:76-84): region 0 and w4 region 1 (voigt.c:95-96) are
-// evaluated inline; only lanes closer to the centre than xlim1 call wells_inner().
+// evaluated inline.  Lanes closer to the centre than xlim1 add nothing here: the function
+// reports whether the tile may hold such points, and general_ranges() sums the inner points of
+// a whole batch of lines afterwards (inner_batch), into the wavefront's LDS sums.
 template <int P>
-__device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
+__device__ __forceinline__ bool general_line(const LineWing & l, const LineCore & c,
                                              int i0, int i1, int lane,
                                              const double (&v)[P], double (&acc)[P])
 {
     if (l.last < i0 || l.first > i1)
     {
-        return;     // also skips empty windows
+        return false;     // also skips empty windows
     }
     const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
     const double yq = c.y*c.y;
@@ -190,6 +192,7 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
     const double d0 = a0*a0;
     const double d2 = yq + yq - 1.;
     const double r1_scale = c.amp*rsqrpi*c.y;
+    bool core_row = false;
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
@@ -210,6 +213,7 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
         }
         else
         {
+            core_row = true;
             const double xi = d*c.repwid;               // voigt.c:76
             const double abx = fabs(xi);
             const double xq = abx*abx;
@@ -228,13 +232,11 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
                                   rcp_newton(__builtin_fma(xq, d2 + xq, d0));
                 value = mid ? w4 : value;
             }
-            if (!far && !mid)
-            {
-                value = c.amp*wells_inner(xi, c.y);
-            }
         }
         acc[p] += inside ? value : 0.;
     }
+    // May the tile hold inner points of this line?  (xlim1 == 0: the line has none at all.)
+    return core_row && c.xlim1 > 0.;
 }
 
 // Up to five index ranges of lines in general position, walked as one list; records are
@@ -258,28 +260,237 @@ __device__ __forceinline__ int general_index(const GeneralList & g, int k)
     return g.begin[4] + k;
 }
 
+// The inner points (|x| < xlim1: w4 regions 2-3, CPF12) of a batch of lines, packed twice.
+// Row by row they would leave most of a wavefront idle in the most expensive branches of the
+// profile: a line's inner points are a few dozen consecutive grid points (27 for a CO2 line at
+// 1000 cm-1 and 0.001 cm-1 spacing, a few hundred at 5000 cm-1 and 0.0005 cm-1), and within them
+// the three classes of voigt_profile.h -- costing roughly 35, 120 and 190 instruction slots per
+// point -- each hold a part of the lanes while the wavefront pays for all three.
+//   step 1, lane = line:  fetch the line's scalars, clip its inner index range to tile and
+//                         window, inclusive scan of the segment lengths (the segments of all
+//                         queued lines laid end to end);
+//   step 2, lane = point: for every 64 positions of that sequence, find the line and grid point
+//                         of each lane, form x, classify with the reference's comparisons, and
+//                         append (line, point) to the class's list (ballot + prefix count);
+//   step 3, lane = entry of ONE class list, whenever a list holds 64 entries (and at the end):
+//                         evaluate that class's formula, and add to `slab` (LDS sums of the
+//                         wavefront, index = point - tile_first) one line at a time: two lines of
+//                         a list may cover the same grid point, and the order of additions is
+//                         fixed -- results do not depend on scheduling.
+constexpr int kInnerQueue = 32;         // lines per batch
+constexpr int kInnerList = 128;         // entries a class list can hold (64 left + 64 new)
+
+struct InnerStage
+{
+    int line[kInnerQueue];              // the queue: lines of the batch with a core row in the tile
+    int first[kInnerQueue];             // first inner point in tile and window
+    int begin[kInnerQueue], end[kInnerQueue];   // the line's segment in the packed sequence
+    double centre[kInnerQueue], repwid[kInnerQueue], y[kInnerQueue], amp[kInnerQueue];
+    double xlim1[kInnerQueue];
+    unsigned short list[kInnerClasses][kInnerList];     // (queue slot << 9) | (point - tile_first)
+};
+
+template <int C>
+__device__ __forceinline__ void inner_evaluate(InnerStage & stage, int count, int i0, int v0,
+                                               double dv, int lane, double * slab)
+{
+    const bool active = lane < count;
+    const unsigned record = stage.list[C][active ? lane : 0];
+    const int q = record >> 9;
+    const int offset = record & 511;
+    // absorption.c:39: v[i] = v0 + i*dv (product rounded, then the sum); voigt.c:76-78.
+    const double v = (double)v0 + (double)(i0 + offset)*dv;
+    const double xi = (v - stage.centre[q])*stage.repwid[q];
+    double value = 0.;
+    if (active)
+    {
+        const double y = stage.y[q];
+        const double k = C == 0 ? inner_class_a(xi, y)
+                       : (C == 1 ? inner_class_b(xi, y) : inner_class_c(xi, y));
+        value = stage.amp[q]*k;
+    }
+    unsigned long long left = __ballot(active);
+    while (left != 0)
+    {
+        const int q0 = __builtin_amdgcn_readlane(q, __builtin_ctzll(left));
+        const bool now = active && q == q0;
+        if (now)
+        {
+            slab[offset] += value;
+        }
+        left &= ~__ballot(now);
+    }
+}
+
+__device__ __forceinline__ void inner_batch(const LineWing * __restrict__ wing,
+                                            const LineCore * __restrict__ core,
+                                            InnerStage & stage, int queued, int i0, int i1,
+                                            int v0, int n_per_v, double dv, int lane,
+                                            double * slab)
+{
+    // Step 1.
+    unsigned long long todo;
+    int total;
+    {
+        const bool has = lane < queued;
+        const int j = stage.line[has ? lane : 0];
+        const double centre = wing[j].centre;
+        const int window_first = wing[j].first, window_last = wing[j].last;
+        const double repwid = core[j].repwid, xlim1 = core[j].xlim1;
+        int first, last;
+        inner_index_range(centre, repwid, xlim1, v0, n_per_v, first, last);
+        first = max(max(first, window_first), i0);
+        last = min(min(last, window_last), i1);
+        const int length = (has && last >= first) ? last - first + 1 : 0;
+        int inclusive = length;
+#pragma unroll
+        for (int offset = 1; offset < kInnerQueue; offset <<= 1)
+        {
+            const int below = __shfl_up(inclusive, offset, 64);
+            inclusive += (lane >= offset) ? below : 0;
+        }
+        if (lane < kInnerQueue)
+        {
+            stage.first[lane] = first;
+            stage.begin[lane] = inclusive - length;
+            stage.end[lane] = inclusive;
+            stage.centre[lane] = centre;
+            stage.repwid[lane] = repwid;
+            stage.y[lane] = core[j].y;
+            stage.amp[lane] = core[j].amp;
+            stage.xlim1[lane] = xlim1;
+        }
+        total = __builtin_amdgcn_readlane(inclusive, kInnerQueue - 1);
+        todo = __ballot(length > 0);
+    }
+
+    int count[kInnerClasses] = {0, 0, 0};
+    for (int base = 0; ; base += 64)
+    {
+        const bool drain = base >= total;
+        if (!drain)
+        {
+            // Step 2.
+            const int u = base + lane;
+            double m_centre = 0., m_repwid = 1., m_y = 100., m_xlim1 = 0.;
+            int m_point = i0, m_line = -1;
+            unsigned long long scan = todo;
+            while (scan != 0)
+            {
+                const int q = __builtin_ctzll(scan);
+                const int begin = __builtin_amdgcn_readfirstlane(stage.begin[q]);
+                if (begin >= base + 64)
+                {
+                    break;
+                }
+                const int end = __builtin_amdgcn_readfirstlane(stage.end[q]);
+                const bool mine = u >= begin && u < end;
+                m_centre = mine ? stage.centre[q] : m_centre;
+                m_repwid = mine ? stage.repwid[q] : m_repwid;
+                m_y = mine ? stage.y[q] : m_y;
+                m_xlim1 = mine ? stage.xlim1[q] : m_xlim1;
+                m_point = mine ? stage.first[q] + (u - begin) : m_point;
+                m_line = mine ? q : m_line;
+                if (end <= base + 64)
+                {
+                    todo &= ~(1ull << q);       // this line's segment ends here
+                }
+                scan &= scan - 1;
+            }
+            const double v = (double)v0 + (double)m_point*dv;
+            const double abx = fabs((v - m_centre)*m_repwid);
+            const bool take = m_line >= 0 && abx < m_xlim1;
+            const int cls = inner_class(abx, inner_limits(m_y));
+            const unsigned short record = (unsigned short)((m_line << 9) | (m_point - i0));
+#pragma unroll
+            for (int c = 0; c < kInnerClasses; ++c)
+            {
+                const bool member = take && cls == c;
+                const unsigned long long mask = __ballot(member);
+                if (member)
+                {
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    stage.list[c][count[c] + rank] = record;
+                }
+                count[c] += __builtin_popcountll(mask);
+            }
+        }
+        // Step 3.
+#pragma unroll
+        for (int c = 0; c < kInnerClasses; ++c)
+        {
+            if (count[c] >= 64 || (drain && count[c] > 0))
+            {
+                const int now = min(count[c], 64);
+                if (c == 0) inner_evaluate<0>(stage, now, i0, v0, dv, lane, slab);
+                if (c == 1) inner_evaluate<1>(stage, now, i0, v0, dv, lane, slab);
+                if (c == 2) inner_evaluate<2>(stage, now, i0, v0, dv, lane, slab);
+                count[c] -= now;
+                // What is left (fewer than 64 entries) moves to the front of the list.
+                const unsigned short rest = stage.list[c][64 + lane];
+                if (lane < count[c])
+                {
+                    stage.list[c][lane] = rest;
+                }
+            }
+        }
+        if (drain)
+        {
+            break;
+        }
+    }
+}
+
+// Lines are walked in batches: first the rows of every line of the batch (registers), noting
+// in `stage.line` (LDS, this wavefront's) which lines may have inner points in the tile,
+// then those points in one place (inner_batch) -- the two halves need different registers, and
+// kept apart neither pays for the other's.
 template <int P>
 __device__ __forceinline__ void general_ranges(const LineWing * __restrict__ wing,
                                                const LineCore * __restrict__ core,
                                                const GeneralList & g, int i0, int i1, int lane,
-                                               const double (&v)[P], double (&acc)[P])
+                                               int v0, int n_per_v, double dv,
+                                               const double (&v)[P], double (&acc)[P],
+                                               double * slab, InnerStage & stage, int ablate = 0)
 {
     const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
     int k = 0;
-    for (; k + 2 <= total; k += 2)
+    while (k < total)
     {
-        const int ja = general_index(g, k), jb = general_index(g, k + 1);
-        const LineWing la = wing[ja], lb = wing[jb];
-        const LineCore ca = core[ja], cb = core[jb];
-        general_line<P>(la, ca, i0, i1, lane, v, acc);
-        general_line<P>(lb, cb, i0, i1, lane, v, acc);
-    }
-    if (k < total)
-    {
-        const int ja = general_index(g, k);
-        const LineWing la = wing[ja];
-        const LineCore ca = core[ja];
-        general_line<P>(la, ca, i0, i1, lane, v, acc);
+        int queued = 0;
+        for (; k + 2 <= total && queued + 2 <= kInnerQueue; k += 2)
+        {
+            const int ja = general_index(g, k), jb = general_index(g, k + 1);
+            const LineWing la = wing[ja], lb = wing[jb];
+            const LineCore ca = core[ja], cb = core[jb];
+            if (general_line<P>(la, ca, i0, i1, lane, v, acc))
+            {
+                if (lane == 0) stage.line[queued] = ja;
+                ++queued;
+            }
+            if (general_line<P>(lb, cb, i0, i1, lane, v, acc))
+            {
+                if (lane == 0) stage.line[queued] = jb;
+                ++queued;
+            }
+        }
+        if (k + 1 == total && queued < kInnerQueue)
+        {
+            const int ja = general_index(g, k);
+            const LineWing la = wing[ja];
+            const LineCore ca = core[ja];
+            if (general_line<P>(la, ca, i0, i1, lane, v, acc))
+            {
+                if (lane == 0) stage.line[queued] = ja;
+                ++queued;
+            }
+            ++k;
+        }
+        if (queued > 0 && !(ablate & 32))       // (32: diagnostics, leaves the inner points out)
+        {
+            inner_batch(wing, core, stage, queued, i0, i1, v0, n_per_v, dv, lane, slab);
+        }
     }
 }
 
@@ -299,7 +510,8 @@ __device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, in
 // four partial sums meet in LDS and each wavefront finishes P/4 of the rows (scaling, the
 // one store of k -- or of the item's partial sums when the tile was split).
 template <int P>
-__global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
+__global__ __launch_bounds__(256)
+void accumulate_kernel(const AccumulateArgs a)
 {
     __shared__ double partial[4][P][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -315,6 +527,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     const LineCore * __restrict__ core = a.core + (long long)level*a.n_lines;
 
     double v[P], acc[P];
+    // This wavefront's block of the LDS sums: what inner_pass() adds to while the lines are
+    // walked, and where the register sums join it at the end.
+    double * slab = &partial[wave][0][0];
+    __shared__ InnerStage inner_stage[4];
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
@@ -323,6 +539,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
         const double step = (double)i*a.dv;
         v[p] = (double)a.v0 + step;
         acc[p] = 0.;
+        partial[wave][p][lane] = 0.;
     }
 
     // This wavefront's share of each of the five cut-point ranges: the item's part of the
@@ -353,13 +570,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     }
     if (!(a.ablate & 1))
     {
-        general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
+        general_ranges<P>(wing, core, g, i0, i1, lane, a.v0, a.n_per_v, a.dv, v, acc, slab,
+                          inner_stage[wave], a.ablate);
     }
 
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
-        partial[wave][p][lane] = acc[p];
+        partial[wave][p][lane] += acc[p];
     }
     __syncthreads();
 

@@ -1389,7 +1389,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->aligned_tiles = (int)value;
     }
-    else if (key == "ablate" && value >= 0 && value <= 31)
+    else if (key == "ablate" && value >= 0 && value <= 127)
     {
         engine->ablate = (int)value;    // timing diagnostics only: results are wrong when set
     }

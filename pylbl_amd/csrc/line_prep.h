@@ -165,4 +165,20 @@ __host__ __device__ inline int prepare_line(const LevelScalars & lv, const GridS
     return status;
 }
 
+// Grid indices that may fall inside |x| < xlim1, the inner regions of a line (w4 regions 2-3,
+// CPF12; voigt.c:98-186): conservative, with the margins of core_first / core_last above.
+__host__ __device__ inline void inner_index_range(double centre, double repwid, double xlim1,
+                                                  int v0, int n_per_v, int & first, int & last)
+{
+    const double near = (xlim1/repwid)*(1. + 1.e-9);
+    double lo = floor((centre - near - (double)v0)*n_per_v) - 1.;
+    double hi = floor((centre + near - (double)v0)*n_per_v) + 2.;
+    if (lo < -1.e9) lo = -1.e9;
+    if (hi > 1.e9) hi = 1.e9;
+    if (hi < -1.e9) hi = -1.e9;
+    if (lo > 1.e9) lo = 1.e9;
+    first = (int)lo;
+    last = (int)hi;
+}
+
 }  // namespace lbl

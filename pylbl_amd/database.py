@@ -223,20 +223,37 @@ class MemoryDatabase(object):
     lines backend and ``Spectroscopy`` need -- ``molecules()``, ``line_table(name)``,
     ``gas(name)``, ``tips(name)`` -- behaves like the file-backed class, including
     AliasNotFoundError for an unknown name."""
-    def __init__(self, tables, aliases=None):
+    def __init__(self, tables, aliases=None, cross_sections=None):
+        """cross_sections: optional {formula: path of its ARTS-crossfit coefficient file}, what
+        the artscrossfit table holds in a file-backed database."""
         self.path = None
         self.tables = {table.formula: table for table in tables}
         self.aliases = {}
         for formula, names in (aliases or {}).items():
             for name in names:
                 self.aliases[name] = formula
+        self.cross_sections = dict(cross_sections or {})
 
     def molecules(self):
-        return list(self.tables)
+        return list(self.tables) + [x for x in self.cross_sections if x not in self.tables]
+
+    def arts_crossfit(self, name):
+        """Same outcomes as Database.arts_crossfit (pyLBL/database.py:397-415)."""
+        formula = self.aliases.get(name, name)
+        if formula in self.cross_sections:
+            return self.cross_sections[formula]
+        if formula not in self.tables:
+            raise AliasNotFoundError(f"{name} not found in database.")
+        raise CrossSectionNotFoundError(f"No cross sections for {name}.")
 
     def line_table(self, name):
         formula = self.aliases.get(name, name)
         if formula not in self.tables:
+            if formula in self.cross_sections:
+                # A molecule the database knows only through its cross-sections: the reference's
+                # ingest gives it a molecule row and an alias but no TIPS rows or transitions
+                # (pyLBL/database.py:213-262), i.e. a zero lines spectrum, not an error.
+                raise TipsDataNotFoundError(f"tips data not found for molecule {name}.")
             raise AliasNotFoundError(f"{name} not found in database.")
         table = self.tables[formula]
         if table.tips_data is None or np.size(table.tips_data) == 0:

@@ -21,9 +21,18 @@ allowance for the pedestal, see test_gpu_zz_tolerance_report.py):
               call; the surface and the 10 Pa level compared at all 3 M points with pedestal on
               and off, the levels between through windows.
   configs[4]  shape: 1-5000 @ 0.0005 (n_per_v = 2000, 10 M points), 4 levels of the 256-level
-              atmosphere; CO / O2 / N2 at all points with pedestal on and off, H2O / CO2 through
-              windows, all levels.
+              atmosphere; CO / O2 / N2 at all points with pedestal on and off at two levels; all
+              eight molecules through windows at all four levels; H2O, CO2, O3, N2O and CH4 at
+              all 10 M points, pedestal on and off, at one stratospheric level (level 170,
+              ~1 hPa); and ONE GPU'S SHARE of the 8-GPU job -- 32 levels x 8 molecules summed on
+              the device through ShardedLines.for_engine -- through windows against the
+              composition of the oracle's spectra.
   banded      a banded CO2 table (split tiles, long pedestal chain) at 5 M points, pedestal on.
+  far-field   configs[1] and the target again with the far-field series (what Spectroscopy runs
+              by default), every point, pedestal on and off, same 1e-6 bar.
+  end to end  Spectroscopy.compute_absorption() with default arguments at 5 M points, one
+              level, H2O + CO2 + a cross-section-only gas: the three mechanism slots against the
+              three oracles.
 """
 import warnings
 
@@ -44,6 +53,8 @@ STANDARD8 = synthetic.standard_atmosphere(8)
 STANDARD256 = synthetic.standard_atmosphere(256)
 LEVELS256 = (0, 85, 170, 255)
 SMALL = ("CO", "O2", "N2")
+LARGE = ("H2O", "CO2", "O3", "N2O", "CH4")
+FULL_LEVEL = 170
 BANDED = ("banded", "CO2", 1., 5000., 300_000, 8, 41)
 
 
@@ -89,6 +100,11 @@ def farm():
             for ped in (False, True):
                 f.submit(("c4", formula, level, ped), uniform(formula), t, p, x, 1, 5001, 2000,
                          ped)
+    for formula in LARGE:
+        t, p, x = level_of(STANDARD256, formula, FULL_LEVEL)
+        for ped in (False, True):
+            f.submit(("c4", formula, FULL_LEVEL, ped), uniform(formula), t, p, x, 1, 5001, 2000,
+                     ped)
     # banded table, pedestal on (+ the plain spectrum its tolerance refers to)
     t, p, x = level_of(SURFACE, "CO2", 0)
     for ped in (False, True):
@@ -214,9 +230,9 @@ def test_config3_shape_standard_atmosphere(farm, engine, oracle):
 
 
 def test_config4_shape_ten_million_points(farm, engine, oracle):
-    """n_per_v = 2000: windows of 102 001 points, tiles of 512."""
+    """n_per_v = 2000: windows of 102 001 points, tiles of 512.  All eight molecules."""
     t4, p4 = STANDARD256.t[list(LEVELS256)], STANDARD256.p[list(LEVELS256)]
-    for formula in SMALL + ("H2O", "CO2"):
+    for formula in SMALL + LARGE:
         table = table_from_recipe(uniform(formula))
         x4 = STANDARD256.vmr[formula][list(LEVELS256)]
         handle = engine.load(table)
@@ -235,6 +251,137 @@ def test_config4_shape_ten_million_points(farm, engine, oracle):
                                   2000, (1, 1200 + 301*row, 4999),
                                   f"config4 {formula} level {LEVELS256[row]}", width=1)
         engine.free(handle)
+
+
+@pytest.mark.parametrize("formula", LARGE)
+def test_config4_large_molecules_every_point(farm, engine, formula):
+    """The five molecules with 1e5 - 4e5 lines at n_per_v = 2000, all 10 M points, pedestal off
+    and on, at a ~1 hPa level (narrow cores: the CPF12 rows of the general path)."""
+    t, p, x = level_of(STANDARD256, formula, FULL_LEVEL)
+    handle = engine.load(table_from_recipe(uniform(formula)))
+    for ped in (False, True):
+        k, evals = engine.compute(handle, t, p, x, 1, 5001, 2000, remove_pedestal=ped,
+                                  want_evals=True)
+        check_full(farm, ("c4", formula, FULL_LEVEL, False), ("c4", formula, FULL_LEVEL, ped),
+                   k[0], 1, 5001, 2000, ped, f"config4 {formula} level {FULL_LEVEL} ped={ped}",
+                   evals)
+    engine.free(handle)
+
+
+def test_config4_one_gpus_share_through_the_sharded_path(engine, oracle):
+    """configs[4] on 8 GPUs gives each 32 levels x 8 molecules x 10 M points; with
+    output="total" the sum over gases is formed on the device (2.56 GB instead of 20.5 GB per
+    GPU).  Exactly that call -- pylbl_amd.distributed.ShardedLines.for_engine, what
+    bench.py --gpus 8 --config 4 --levels-per-gpu 32 --output total runs on every rank -- on
+    rank 3's block of levels (96..127), windows of several levels against the oracle's
+    n x k summed over the eight molecules."""
+    from pylbl_amd import distributed, number_density
+    formulas = SMALL + LARGE
+    mine = distributed.level_shard(256, 3, 8)
+    assert (mine.start, mine.stop) == (96, 128)
+    t, p = STANDARD256.t[mine], STANDARD256.p[mine]
+    vmr = {f: STANDARD256.vmr[f][mine] for f in formulas}
+    tables = {f: table_from_recipe(uniform(f)) for f in formulas}
+    handles = {f: engine.load(tables[f]) for f in formulas}
+    sharded = distributed.ShardedLines.for_engine(
+        engine, handles, (1, 5001, 2000), remove_pedestal=False, scale_density=True,
+        weights=[tables[f].num_lines for f in formulas])
+    total = sharded.run(t, p, vmr, output="total")
+    assert tuple(total.shape) == (32, 10_000_000)
+    npv = 2000
+    for row in (0, 13, 31):
+        for lo in (1, 667 + 97*row, 2349, 4999):
+            g0, g1 = max(lo - 2, 1), min(lo + 3, 5001)
+            expect = np.zeros(npv)
+            for f in formulas:
+                near = tables[f].subset((tables[f].nu >= g0 - 26.) & (tables[f].nu <= g1 + 26.))
+                k_ref, _ = oracle.absorption_port(near, t[row], p[row], vmr[f][row], g0, g1, npv)
+                expect += number_density(t[row], p[row], vmr[f][row]) * \
+                    k_ref[(lo - g0)*npv:(lo + 1 - g0)*npv]
+            got = total[row, (lo - 1)*npv:lo*npv].cpu().numpy()
+            np.testing.assert_allclose(got, expect, rtol=1e-6,
+                                       err_msg=f"baseline config4 share level {96 + row} @{lo}")
+    for handle in handles.values():
+        engine.free(handle)
+
+
+@pytest.mark.parametrize("name,npv", [("c1", 100), ("target", 1000)])
+def test_h2o_co2_whole_grid_farfield_series(farm, engine, name, npv):
+    """What Spectroscopy runs unless told otherwise (farfield=True): lines far from a tile enter
+    through the tile's power series.  Every point of configs[1] and of the target, pedestal off
+    and on, against the oracle at the same bar as the direct kernel."""
+    for formula in ("H2O", "CO2"):
+        t, p, x = level_of(SURFACE, formula, 0)
+        handle = engine.load(table_from_recipe(uniform(formula)))
+        for ped in (False, True):
+            k, evals = engine.compute(handle, t, p, x, 1, 5001, npv, remove_pedestal=ped,
+                                      want_evals=True, farfield=True)
+            check_full(farm, (name, formula, False), (name, formula, ped), k[0], 1, 5001, npv,
+                       ped, f"{name} {formula} far-field ped={ped}", evals)
+        engine.free(handle)
+
+
+def test_spectroscopy_default_call_end_to_end(farm, engine, continuum_oracle, tmp_path):
+    """Spectroscopy(atmosphere, grid, database).compute_absorption() -- every argument at its
+    default: output "all", pedestal removed because the continuum is MT-CKD, far-field series
+    on -- for the target workload (1 level, H2O + CO2, 1-5000 @ 0.001) plus O2 and N2 (the
+    continua need their mole fractions, and a gas of the atmosphere that the database does not
+    know is an error in the reference) and a gas that only has a cross-section.  Slot 0 against the farm's whole-grid oracle spectra, slot 1 against the
+    MT-CKD oracle, slot 2 against the cross-section oracle, all 4 999 000 points."""
+    from oracle import xsec_oracle
+    from pylbl_amd import MemoryDatabase, Spectroscopy, arts_crossfit, number_density
+    bands = synthetic.cross_section_bands(seed=5)
+    arts_crossfit.write_npz(tmp_path / "CFC11.npz", bands)
+    with_lines = {"H2O": "target", "CO2": "target", "O2": "c2", "N2": "c2"}
+    tables = [table_from_recipe(uniform(f)) for f in with_lines]
+    database = MemoryDatabase(tables, cross_sections={"CFC11": str(tmp_path / "CFC11.npz")})
+    gases = {"H2O": SURFACE.vmr["H2O"], "CO2": SURFACE.vmr["CO2"], "O2": SURFACE.vmr["O2"],
+             "N2": SURFACE.vmr["N2"], "CFC11": np.asarray([2.3e-10])}
+    atmosphere = synthetic.Atmos(p=SURFACE.p, t=SURFACE.t, vmr=gases)
+    grid = np.arange(1., 5000., 0.001)
+    spec = Spectroscopy(atmosphere, grid, database)
+    assert spec.farfield and spec.continua_backend == "mt_ckd"
+    out = spec.compute_absorption()
+    assert list(out["mechanism"]) == ["lines", "continuum", "cross_section"]
+    t, p = float(SURFACE.t[0]), float(SURFACE.p[0])
+    vmr = {g: float(v[0]) for g, v in gases.items()}
+    for formula in gases:
+        beta = np.asarray(out[f"{formula}_absorption"])
+        assert beta.shape == (1, 3, grid.size)
+        n = number_density(t, p, vmr[formula])
+        # slot 0
+        if formula in with_lines:
+            k_ref, _ = farm.result((with_lines[formula], formula, True))
+            k_plain, _ = farm.result((with_lines[formula], formula, False))
+            assert_spectrum(beta[0, 0], n*k_ref[:grid.size], case_for(1, 5001, 1000, True),
+                            f"baseline end-to-end {formula} lines", n*k_plain[:grid.size])
+        else:
+            assert not beta[0, 0].any()
+        # slot 1
+        owners = {"H2O": ["H2OForeign", "H2OSelf"], "CFC11": []}.get(formula, [formula])
+        expect = np.zeros(grid.size)
+        for owner in owners:
+            expect = expect + continuum_oracle.continuum(owner).spectra(t, p, vmr, grid)
+        scale = np.max(np.abs(expect))
+        assert np.all(np.abs(beta[0, 1] - expect) <= 1e-6*np.abs(expect) + 1e-12*scale), formula
+        # slot 2
+        if formula == "CFC11":
+            expect = n*xsec_oracle.absorption_coefficient(bands, grid, t, p)
+            scale = np.max(np.abs(expect))
+            assert scale > 0.
+            assert np.all(np.abs(beta[0, 2] - expect) <= 1e-6*np.abs(expect) + 1e-12*scale)
+        else:
+            assert not beta[0, 2].any()
+    # "gas" and "total" of the same call: sums of the slots above, formed on the device.
+    per_gas = spec.compute_absorption("gas")
+    total = spec.compute_absorption("total")
+    summed = np.zeros((1, grid.size))
+    for formula in gases:
+        mine = np.asarray(out[f"{formula}_absorption"]).sum(axis=1)
+        got = np.asarray(per_gas[f"{formula}_absorption"])
+        assert np.all(np.abs(got - mine) <= 1e-12*np.max(np.abs(mine)) + 1e-300), formula
+        summed += mine
+    assert np.all(np.abs(np.asarray(total["absorption"]) - summed) <= 1e-12*np.max(summed))
 
 
 def test_banded_table_whole_grid_pedestal(farm, engine):
