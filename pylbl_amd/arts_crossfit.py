@@ -20,13 +20,17 @@ from .mt_ckd import resident_grid
 
 
 def _as_matrix(coefficients, size):
-    """[4, nfreq] whichever way the file stores it (the reference transposes what xarray
-    hands it, cross_section.py:40)."""
+    """[4, nfreq] from what the file stores.  The reference transposes what xarray hands it and
+    then indexes ``coeffs[i, :]`` for the four fit terms (cross_section.py:40,
+    xsec_aux_functions.py:50-52): its files hold ``band<m>_coeffs`` as [nfreq, 4], and that
+    reading comes first (a band of exactly four frequencies is the case where the shape alone
+    does not tell).  The other orientation, which the reference could not read, is accepted for
+    conversions made elsewhere."""
     c = np.asarray(coefficients, dtype=np.float64)
-    if c.shape == (4, size):
-        return c
     if c.shape == (size, 4):
         return np.ascontiguousarray(c.T)
+    if c.shape == (4, size):
+        return c
     raise ValueError(f"coefficients of shape {c.shape} do not match {size} frequencies.")
 
 
@@ -58,7 +62,9 @@ def write_npz(path, bands):
     arrays = {"bands": np.arange(len(bands))}
     for m, (frequency, coefficients) in enumerate(bands):
         arrays[f"band{m}_fgrid"] = np.asarray(frequency, dtype=np.float64)
-        arrays[f"band{m}_coeffs"] = np.asarray(coefficients, dtype=np.float64)
+        # stored like the reference's files: [nfreq, 4]
+        arrays[f"band{m}_coeffs"] = np.ascontiguousarray(np.asarray(coefficients,
+                                                                   dtype=np.float64).T)
     np.savez_compressed(path, **arrays)
 
 

@@ -168,3 +168,24 @@ def test_spectroscopy_cross_section_slot(tmp_path):
     assert not np.asarray(off.compute_absorption()["N2O_absorption"])[:, 2].any()
     with pytest.raises(KeyError):
         Spectroscopy(atmos, grid, None, cross_sections_backend="not-a-model")
+
+
+def test_coefficient_file_in_the_reference_layout():
+    """The netCDF-4 file of tests/golden (layout of cross_section.py:29-41) through
+    CrossSection on the GPU against what the reference's own class returned for it
+    (tests/golden/make_xsec_layout.py)."""
+    from tests.test_xsec_oracle import _layout_paths
+    try:
+        from pylbl_amd import hdf5_reader
+        hdf5_reader.library()
+    except OSError as error:
+        pytest.skip(str(error))
+    path, expected = _layout_paths()
+    cross = arts_crossfit.CrossSection("CFC11", str(path))
+    assert cross.sizes == [241, 97, 4, 161]
+    with np.load(expected) as data:
+        for name in ("fine", "coarse", "knots"):
+            grid = data[f"grid_{name}"]
+            for i, (temperature, pressure) in enumerate(data["states"]):
+                got = cross.absorption_coefficient(grid, temperature, pressure)
+                assert_close(got, data[f"xsec_{name}_{i}"], f"{name} state {i}")

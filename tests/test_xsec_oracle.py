@@ -96,3 +96,70 @@ def test_hdf5_coefficient_file(tmp_path):
         assert np.array_equal(f, f2) and np.array_equal(c, c2)
     with pytest.raises(OSError):
         hdf5_reader.File(tmp_path / "absent.nc")
+
+
+def _layout_paths():
+    import pathlib
+    golden = pathlib.Path(__file__).resolve().parent / "golden"
+    return golden / "xsec_layout.nc", golden / "xsec_layout.npz"
+
+
+def test_reader_returns_what_the_reference_reads_from_its_file_layout():
+    """tests/golden/xsec_layout.nc is laid out as cross_section.py:29-41 reads its files
+    (`bands`, `band<m>_fgrid`, `band<m>_coeffs` stored [nfreq, 4], band numbers not 0..n-1, one
+    band of exactly four frequencies, one stored in descending order); xsec_layout.npz holds
+    what the REFERENCE'S OWN CrossSection.absorption_coefficient returned for it
+    (tests/golden/make_xsec_layout.py).  hdf5_reader + read_bands + the oracle must give the
+    same, and so must the reference's sequence of calls replayed over this package's reader."""
+    from scipy.interpolate import interp1d
+    from oracle import xsec_oracle
+    try:
+        from pylbl_amd import hdf5_reader
+        hdf5_reader.library()
+    except OSError as error:
+        pytest.skip(str(error))
+    path, expected = _layout_paths()
+    with hdf5_reader.File(path) as source:
+        numbers = [int(m) for m in source.array("bands")]
+        assert numbers == [1, 2, 3, 5]
+        stored = {m: (source.array(f"band{m}_fgrid"), source.array(f"band{m}_coeffs"))
+                  for m in numbers}
+    assert [stored[m][1].shape for m in numbers] == [(241, 4), (97, 4), (4, 4), (161, 4)]
+    bands = arts_crossfit.read_bands(path)
+    for m, (frequency, coefficients) in zip(numbers, bands):
+        order = np.argsort(stored[m][0], kind="mergesort")
+        assert np.array_equal(frequency, stored[m][0][order])
+        # the reference's transposes: coeffs_m = stored.transpose() -> [4, nfreq]
+        assert np.array_equal(coefficients, stored[m][1].transpose()[:, order])
+    with np.load(expected) as data:
+        states = data["states"]
+        for name in ("fine", "coarse", "knots"):
+            grid = data[f"grid_{name}"]
+            for i, (temperature, pressure) in enumerate(states):
+                want = data[f"xsec_{name}_{i}"]
+                # read_bands hands the bands over in ascending frequency (what interp1d makes of
+                # them anyway); for the band stored descending the clipping rule's sums then
+                # run in the other order: last-bit differences, same points clipped.
+                got = xsec_oracle.absorption_coefficient(bands, grid, temperature, pressure)
+                assert np.array_equal(got == 0., want == 0.), (name, i)
+                assert np.max(np.abs(got - want)) <= 1e-13*np.max(want), (name, i)
+                # cross_section.py:29-47 replayed over this package's reader
+                replay = np.zeros(grid.shape)
+                for m in numbers:
+                    freq_data = stored[m][0].transpose()
+                    coeffs_m = stored[m][1].transpose()
+                    xsec_temp = xsec_oracle.full_model(temperature, pressure, coeffs_m)
+                    replay = replay + interp1d(freq_data, xsec_temp, fill_value=0.,
+                                               bounds_error=False)(grid*299792458.0*100)
+                assert np.array_equal(replay, want), (name, i)
+
+
+def test_npz_conversion_keeps_the_reference_orientation(tmp_path):
+    bands = synthetic.cross_section_bands(seed=9, ranges=((10., 10.41),), spacing=0.1)
+    assert bands[0][0].size == 4                # four frequencies: the ambiguous shape
+    arts_crossfit.write_npz(tmp_path / "x.npz", bands)
+    with np.load(tmp_path / "x.npz") as archive:
+        assert archive["band0_coeffs"].shape == (4, 4)
+        assert np.array_equal(archive["band0_coeffs"], bands[0][1].T)
+    (frequency, coefficients), = arts_crossfit.read_bands(tmp_path / "x.npz")
+    assert np.array_equal(frequency, bands[0][0]) and np.array_equal(coefficients, bands[0][1])
