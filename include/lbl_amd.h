@@ -93,6 +93,21 @@ int lbl_compute(lbl_engine *engine, int32_t molecule, int32_t n_levels,
                 int32_t remove_pedestal, int32_t range_policy, int32_t flags,
                 double *k, int64_t level_stride, int64_t *evals);
 
+/* lbl_compute into device memory (LBL_OUT_DEVICE required) with the result ALSO delivered to
+ * host memory while the call still computes: the grid is worked through in `pieces` runs of
+ * tiles (1..8), and the first `columns` points of every level of a finished run are copied to
+ * `host` (row l at host + l*host_pitch bytes; page-locked memory from lbl_host_alloc for the
+ * copies to overlap) beside the kernels of the next run.  What the reference's callers get --
+ * a host array per call (gas_optics.py:65,91) -- without a copy behind the last kernel.  The
+ * values are those of lbl_compute (same kernels, same order of additions).  With LBL_ASYNC the
+ * copies are complete after lbl_synchronize. */
+int lbl_compute_streamed(lbl_engine *engine, int32_t molecule, int32_t n_levels,
+                         const double *temperature, const double *pressure, const double *vmr,
+                         int32_t v0, int32_t vn, int32_t n_per_v, int32_t cut_off,
+                         int32_t remove_pedestal, int32_t range_policy, int32_t flags,
+                         double *k, int64_t level_stride, void *host, int64_t host_pitch,
+                         int64_t columns, int32_t pieces);
+
 /* Waits for everything enqueued on the engine (all of its streams). */
 int lbl_synchronize(lbl_engine *engine);
 

@@ -114,10 +114,12 @@ struct Molecule
     struct Plan
     {
         int v0, vn, n_per_v, cut_off, points, aligned, farfield;
+        int pieces = 1;         // the tiles in `pieces` runs of about equal weight (streamed calls)
         int n_items = 0, n_split = 0;
         long long partial_slots = 0;
-        DeviceBuffer<WorkItem> items;
-        DeviceBuffer<SplitTile> split;
+        DeviceBuffer<WorkItem> items;       // piece-major, heaviest first within a piece
+        DeviceBuffer<SplitTile> split;      // piece-major
+        std::vector<int> item_begin, split_begin, tile_begin;   // [pieces + 1] each
     };
     std::vector<std::unique_ptr<Plan>> plans;
 
@@ -148,6 +150,8 @@ struct Lane
     hipEvent_t runs_found = nullptr;
     hipEvent_t queued = nullptr;    // what the copy stream waits for (lbl_copy_rows_to_host)
     hipEvent_t handed_over = nullptr;   // what a caller's stream waits for (lbl_order_stream_after_engine)
+    hipEvent_t piece_done[8] = {};      // behind the last kernel of each piece of a streamed call
+    hipEvent_t piece_summed[8] = {};    // behind a piece's accumulate launch (pedestal: applied elsewhere)
     // The last few writes of device output queued on this lane: where, and an event behind the
     // kernel that wrote.  A call on another lane that touches the same memory waits for it.
     struct Write { const char * begin = nullptr; const char * end = nullptr; hipEvent_t done = nullptr; };
@@ -190,6 +194,8 @@ struct Lane
         HIP_TRY(hipEventCreateWithFlags(&runs_found, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&handed_over, hipEventDisableTiming));
+        for (auto & e : piece_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto & e : piece_summed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto & w : writes) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pedestal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&levels_copied, hipEventDisableTiming));
@@ -209,6 +215,8 @@ struct Lane
         if (runs_found != nullptr) (void)hipEventDestroy(runs_found);
         if (queued != nullptr) (void)hipEventDestroy(queued);
         if (handed_over != nullptr) (void)hipEventDestroy(handed_over);
+        for (auto & e : piece_done) { if (e != nullptr) (void)hipEventDestroy(e); e = nullptr; }
+        for (auto & e : piece_summed) { if (e != nullptr) (void)hipEventDestroy(e); e = nullptr; }
         for (auto & w : writes) { if (w.done != nullptr) (void)hipEventDestroy(w.done); w.done = nullptr; }
         if (levels_copied != nullptr) (void)hipEventDestroy(levels_copied);
         if (main != nullptr) (void)hipStreamDestroy(main);
@@ -579,14 +587,14 @@ int pick_tiling(const lbl_engine * engine, int farfield, int n_per_v, long long 
 // or two, which does not matter for balance); the exact per-level cut points are still the
 // schedule kernel's.
 Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const GridSpec & g,
-                          const Tiling & tiling, int points, hipStream_t stream)
+                          const Tiling & tiling, int points, hipStream_t stream, int pieces = 1)
 {
     for (size_t i = 0; i < m.plans.size(); ++i)
     {
         Molecule::Plan * p = m.plans[i].get();
         if (p->v0 == g.v0 && p->vn == g.vn && p->n_per_v == g.n_per_v &&
             p->cut_off == g.cut_off && p->points == points && p->aligned == tiling.aligned &&
-            p->farfield == farfield)
+            p->farfield == farfield && p->pieces == pieces)
         {
             // Most recently used last.
             std::rotate(m.plans.begin() + i, m.plans.begin() + i + 1, m.plans.end());
@@ -602,6 +610,7 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
     std::unique_ptr<Molecule::Plan> plan(new Molecule::Plan());
     plan->v0 = g.v0; plan->vn = g.vn; plan->n_per_v = g.n_per_v; plan->cut_off = g.cut_off;
     plan->points = points; plan->aligned = tiling.aligned; plan->farfield = farfield;
+    plan->pieces = pieces;
     const int n_tiles = tiling.n_tiles;
     const std::vector<double> & nu = m.column[0];
     std::vector<long long> weight((size_t)n_tiles);
@@ -634,10 +643,38 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
     const long long floor_lines = engine->item_floor > 0 ? engine->item_floor
                                   : (n_tiles < 1024 || farfield) ? 128 : 512;
     const long long target = std::max<long long>(floor_lines, total/(8*1536) + 1);
+    // Streamed calls (lbl_compute_streamed) launch the tiles in `pieces` runs, each followed by
+    // the copy of its columns: runs of about equal weight, every tile counted with a floor that
+    // stands for its fixed cost.
+    plan->tile_begin.assign((size_t)pieces + 1, n_tiles);
+    plan->tile_begin[0] = 0;
+    {
+        const long long unit = std::max<long long>(total/std::max(n_tiles, 1), 1);
+        const long long all = total + unit*n_tiles;
+        long long running = 0;
+        int piece = 1;
+        for (int t = 0; t < n_tiles && piece < pieces; ++t)
+        {
+            running += weight[t] + unit;
+            if (running*pieces >= all*piece)
+            {
+                plan->tile_begin[piece++] = t + 1;
+            }
+        }
+    }
+    std::vector<int> piece_of_tile((size_t)n_tiles, 0);
+    for (int piece = 0; piece < pieces; ++piece)
+    {
+        for (int t = plan->tile_begin[piece]; t < plan->tile_begin[piece + 1]; ++t)
+        {
+            piece_of_tile[t] = piece;
+        }
+    }
     std::vector<WorkItem> items;
     std::vector<SplitTile> split;
     std::vector<long long> item_weight;
     long long slots = 0;
+    plan->split_begin.assign((size_t)pieces + 1, 0);
     for (int t = 0; t < n_tiles; ++t)
     {
         int parts = (int)std::min<long long>(64, (weight[t] + target - 1)/target);
@@ -645,7 +682,8 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
         const int slot = parts > 1 ? (int)slots : -1;
         if (parts > 1)
         {
-            split.push_back(SplitTile{t, parts, slot, 0});
+            split.push_back(SplitTile{t, parts, slot, 0});      // ascending tiles: piece-major
+            plan->split_begin[piece_of_tile[t] + 1] += 1;
             slots += parts;
         }
         for (int k = 0; k < parts; ++k)
@@ -654,10 +692,25 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
             item_weight.push_back(weight[t]/parts);
         }
     }
+    for (int piece = 0; piece < pieces; ++piece)
+    {
+        plan->split_begin[piece + 1] += plan->split_begin[piece];
+    }
     std::vector<int> order(items.size());
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return item_weight[a] > item_weight[b]; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const int pa = piece_of_tile[items[a].tile], pb = piece_of_tile[items[b].tile];
+        return pa != pb ? pa < pb : item_weight[a] > item_weight[b];
+    });
+    plan->item_begin.assign((size_t)pieces + 1, 0);
+    for (const auto & item : items)
+    {
+        plan->item_begin[piece_of_tile[item.tile] + 1] += 1;
+    }
+    for (int piece = 0; piece < pieces; ++piece)
+    {
+        plan->item_begin[piece + 1] += plan->item_begin[piece];
+    }
     std::vector<WorkItem> sorted(items.size());
     for (size_t i = 0; i < items.size(); ++i) sorted[i] = items[order[i]];
     plan->n_items = (int)sorted.size();
@@ -691,6 +744,11 @@ struct ComputeRequest
     int64_t level_stride;
     int64_t * evals;
     double * derived;      // host, n_lines x 8 in row order, single level only
+    // lbl_compute_streamed: the first `columns` points of every level also go to host memory,
+    // piece by piece as the kernels of a piece finish.
+    char * host = nullptr;
+    int64_t host_pitch = 0, columns = 0;
+    int32_t pieces = 1;
 };
 
 int compute(lbl_engine * engine, const ComputeRequest & rq)
@@ -795,7 +853,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
         }
 
-        Molecule::Plan & plan = plan_for(engine, farfield, *m, g, tiling, points, stream);
+        const bool streamed = rq.host != nullptr && out_device && want_k;
+        const int pieces = streamed ? std::max(1, std::min<int>(rq.pieces, std::min(n_tiles, 8)))
+                                    : 1;
+        Molecule::Plan & plan = plan_for(engine, farfield, *m, g, tiling, points, stream, pieces);
 
         // Levels per pass, bounded by the workspace budget.
         const long long per_level = plan.partial_slots*64*points*8 + n_lines*(long long)(sizeof(LineWing) + sizeof(LineCore)) +
@@ -993,51 +1054,126 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             {
                 HIP_TRY(hipStreamWaitEvent(stream, lane.runs_found, 0));
             }
-            engine->timed(kTimeAccumulate, stream, [&] {
-                if (farfield)
-                {
+            if (farfield)
+            {
+                engine->timed(kTimeAccumulate, stream, [&] {
                     dim3 far_grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
                     hipLaunchKernelGGL(farfield_kernel, far_grid, dim3(256), 0, stream,
                                        lane.wing.data, lane.schedule.data, n_lines, tiling, g.v0,
                                        g.n_per_v, g.n, g.dv, lane.far_series.data);
                     HIP_TRY(hipGetLastError());
-                }
-                // One workgroup per work item, heaviest items first.
-                dim3 grid((unsigned)plan.n_items, (unsigned)count);
-                launch_accumulate(points, grid, stream, args);
-                if (plan.n_split > 0)
+                }, 0);
+            }
+            // A piece = a run of tiles: its accumulate launch (+ the sums of its split tiles),
+            // then -- once the pedestal chain has been queued -- the kernel that applies the
+            // pedestal to its points and, for a streamed call, the copy of its columns, which
+            // runs beside the kernels of the next piece.  One piece unless the call is streamed.
+            auto point_range = [&](int piece, long long & q0, long long & q1) {
+                long long unused = 0;
+                q0 = q1 = 0;
+                if (plan.tile_begin[piece + 1] > plan.tile_begin[piece])
                 {
-                    const int units = plan.n_split*points;      // (split tile, 64-point row)
-                    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((units + 3)/4), (unsigned)count),
-                                       dim3(256), 0, stream, args, plan.split.data, plan.n_split,
-                                       64*points);
+                    tile_bounds(tiling, plan.tile_begin[piece], g.n_per_v, g.n, q0, unused);
+                    tile_bounds(tiling, plan.tile_begin[piece + 1] - 1, g.n_per_v, g.n, unused, q1);
+                    q1 += 1;
+                }
+            };
+            // Where a piece is finished: with a pedestal on the stream the chain runs on (the
+            // apply kernels follow it there, while the main stream goes on with the accumulate
+            // launches of the later pieces), else on the main stream.
+            hipStream_t finish_stream = with_pedestal ? ped_stream : stream;
+            auto finish_piece = [&](int piece) {
+                long long q0, q1;
+                point_range(piece, q0, q1);
+                if (q1 <= q0) return;
+                if (with_pedestal)
+                {
+                    if (finish_stream != stream)
+                    {
+                        // (recorded behind this piece's accumulate launch, below)
+                        HIP_TRY(hipStreamWaitEvent(finish_stream, lane.piece_summed[piece], 0));
+                    }
+                    dim3 grid((unsigned)((q1 - q0 + 255)/256), (unsigned)count);
+                    hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, finish_stream,
+                                       sums, sums_stride, target, target_stride,
+                                       lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
+                                       lane.levels.data, (int)q0, (int)q1, g.n_per_v, n_cells,
+                                       (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0,
+                                       (out_device && add_into) ? 1 : 0);
                     HIP_TRY(hipGetLastError());
                 }
-            });
-
+                if (streamed && q0 < rq.columns)
+                {
+                    const long long c1 = std::min<long long>(q1, rq.columns);
+                    HIP_TRY(hipEventRecord(lane.piece_done[piece], finish_stream));
+                    HIP_TRY(hipStreamWaitEvent(engine->copy_stream, lane.piece_done[piece], 0));
+                    // (The runtime's device-to-host copy is a kernel of its own here, not a DMA
+                    // engine; queued beside an accumulate grid it costs the grid nothing, and a
+                    // hand-written copy kernel of 8..1024 workgroups did worse:
+                    // profiles/r03_perf_deliver.txt.)
+                    HIP_TRY(hipMemcpy2DAsync(rq.host + base*rq.host_pitch + q0*8,
+                                             (size_t)rq.host_pitch, target + q0,
+                                             (size_t)target_stride*8, (size_t)(c1 - q0)*8,
+                                             (size_t)count, hipMemcpyDeviceToHost,
+                                             engine->copy_stream));
+                }
+            };
+            // All accumulate launches first, back to back; the chain is queued behind the first
+            // two of a streamed call (the host waits for the run counts inside), and whatever
+            // finishes pieces is queued last.
+            for (int piece = 0; piece < pieces; ++piece)
+            {
+                const int item0 = plan.item_begin[piece], item1 = plan.item_begin[piece + 1];
+                const int split0 = plan.split_begin[piece], split1 = plan.split_begin[piece + 1];
+                engine->timed(kTimeAccumulate, stream, [&] {
+                    if (item1 > item0)
+                    {
+                        // One workgroup per work item, heaviest items first.
+                        AccumulateArgs mine = args;
+                        mine.items = plan.items.data + item0;
+                        dim3 grid((unsigned)(item1 - item0), (unsigned)count);
+                        launch_accumulate(points, grid, stream, mine);
+                    }
+                    if (split1 > split0)
+                    {
+                        const int units = (split1 - split0)*points;     // (split tile, 64-point row)
+                        hipLaunchKernelGGL(combine_kernel,
+                                           dim3((unsigned)((units + 3)/4), (unsigned)count),
+                                           dim3(256), 0, stream, args, plan.split.data + split0,
+                                           split1 - split0, 64*points);
+                        HIP_TRY(hipGetLastError());
+                    }
+                });
+                if (!with_pedestal)
+                {
+                    finish_piece(piece);
+                }
+                else if (finish_stream != stream)
+                {
+                    HIP_TRY(hipEventRecord(lane.piece_summed[piece], stream));
+                }
+            }
             if (with_pedestal)
             {
                 engine->timed(kTimePedestal, ped_stream, [&] {
                     pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
                                     lane.core.data, g, count, n_cells, engine->scan_chain != 0);
                 });
-                if (engine->overlap_pedestal)
-                {
-                    HIP_TRY(hipEventRecord(lane.pedestal_done, lane.side));
-                    HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
-                }
                 if (alternate && out_device && add_into)
                 {
-                    engine->order_after_writers(stream, rq.k, out_bytes, &lane);
+                    engine->order_after_writers(finish_stream, rq.k, out_bytes, &lane);
                 }
-                dim3 grid((unsigned)((n_long + 255)/256), (unsigned)count);
-                hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, stream, sums,
-                                   sums_stride, target, target_stride,
-                                   lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
-                                   lane.levels.data, g.n, g.n_per_v, n_cells,
-                                   (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0,
-                                   (out_device && add_into) ? 1 : 0);
-                HIP_TRY(hipGetLastError());
+                for (int piece = 0; piece < pieces; ++piece)
+                {
+                    finish_piece(piece);
+                }
+                if (finish_stream != stream)
+                {
+                    // Later users of the lane's main stream (and of the block) come after the
+                    // last apply kernel.
+                    HIP_TRY(hipEventRecord(lane.pedestal_done, finish_stream));
+                    HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
+                }
             }
 
             if (!out_device)
@@ -1314,6 +1450,38 @@ int lbl_compute(lbl_engine * engine, int32_t molecule, int32_t n_levels,
     ComputeRequest rq{molecule, n_levels, temperature, pressure, vmr, v0, vn, n_per_v, cut_off,
                       remove_pedestal, range_policy, flags, k, level_stride, evals, nullptr};
     return compute(engine, rq);
+}
+
+int lbl_compute_streamed(lbl_engine * engine, int32_t molecule, int32_t n_levels,
+                         const double * temperature, const double * pressure, const double * vmr,
+                         int32_t v0, int32_t vn, int32_t n_per_v, int32_t cut_off,
+                         int32_t remove_pedestal, int32_t range_policy, int32_t flags,
+                         double * k, int64_t level_stride, void * host, int64_t host_pitch,
+                         int64_t columns, int32_t pieces)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    if (k == nullptr || host == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "k or host is NULL.");
+    if (!(flags & LBL_OUT_DEVICE))
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "lbl_compute_streamed needs LBL_OUT_DEVICE.");
+    }
+    if (columns < 0 || host_pitch < columns*8 || pieces < 1)
+    {
+        return fail(engine, LBL_BAD_ARGUMENT, "need columns >= 0, host_pitch >= 8*columns and "
+                                              "pieces >= 1.");
+    }
+    ComputeRequest rq{molecule, n_levels, temperature, pressure, vmr, v0, vn, n_per_v, cut_off,
+                      remove_pedestal, range_policy, flags, k, level_stride, nullptr, nullptr};
+    rq.host = static_cast<char *>(host);
+    rq.host_pitch = host_pitch;
+    rq.columns = columns;
+    rq.pieces = pieces;
+    const int status = compute(engine, rq);
+    if (status == LBL_OK && !(flags & LBL_ASYNC))
+    {
+        (void)hipStreamSynchronize(engine->copy_stream);
+    }
+    return status;
 }
 
 int lbl_line_scalars(lbl_engine * engine, int32_t molecule, double temperature,

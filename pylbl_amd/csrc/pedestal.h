@@ -797,12 +797,14 @@ __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __re
                                                              const double * __restrict__ cell_sum,
                                                              const double * __restrict__ point_sum,
                                                              const LevelScalars * __restrict__ levels,
-                                                             int n, int n_per_v, int n_cells,
-                                                             int scale_density, int accumulate)
+                                                             int first, int end, int n_per_v,
+                                                             int n_cells, int scale_density,
+                                                             int accumulate)
 {
+    // Points [first, end): the whole grid, or the columns of one piece of a streamed call.
     const int level = blockIdx.y;
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i = first + blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= end) return;
     const int cell = i/n_per_v;
     const bool on_integer = (cell*n_per_v == i);
     const double * table = on_integer ? point_sum : cell_sum;

@@ -24,7 +24,7 @@ RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
 
 EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
-    "lbl_molecule_free", "lbl_compute", "lbl_synchronize", "lbl_set_option", "lbl_timing",
+    "lbl_molecule_free", "lbl_compute", "lbl_compute_streamed", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_order_stream_after_engine", "lbl_order_engine_after_stream",
     "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
@@ -103,6 +103,9 @@ def library():
     lib.lbl_molecule_free.argtypes = [c_void_p, c_int32]
     lib.lbl_compute.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p] + \
                                [c_int32]*7 + [c_void_p, c_int64, i64p]
+    lib.lbl_compute_streamed.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                         c_void_p] + [c_int32]*7 + [c_void_p, c_int64, c_void_p,
+                                                                    c_int64, c_int64, c_int32]
     lib.lbl_synchronize.argtypes = [c_void_p]
     lib.lbl_set_option.argtypes = [c_void_p, c_char_p, c_int64]
     lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
@@ -342,9 +345,14 @@ class Engine(object):
 
     def compute(self, molecule, temperature, pressure, vmr, v0, vn, n_per_v, cut_off=25,
                 remove_pedestal=False, range_policy="reference", out=None, scale_density=False,
-                accumulate=False, asynchronous=False, want_evals=False, farfield=False):
+                accumulate=False, asynchronous=False, want_evals=False, farfield=False,
+                deliver=None, pieces=4):
         """Cross sections [m2] for every level: returns float64[levels, (vn-v0)*n_per_v]
-        (or fills `out`: a host array or a DeviceSpectra)."""
+        (or fills `out`: a host array or a DeviceSpectra).
+
+        deliver: with a device `out`, a float64 [levels, columns] host view with contiguous rows
+        (page-locked: Engine.host_array) that receives the first `columns` points of every level
+        while the call computes, in `pieces` runs of tiles (lbl_compute_streamed)."""
         t, p, x = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure)), \
             _f64(np.atleast_1d(vmr))
         if not (t.shape == p.shape == x.shape and t.ndim == 1):
@@ -367,6 +375,20 @@ class Engine(object):
                     not out.flags["C_CONTIGUOUS"]:
                 raise ValueError("out must be C-contiguous float64[levels, n].")
             pointer = c_void_p(out.ctypes.data)
+        if deliver is not None:
+            if not (flags & OUT_DEVICE) or want_evals:
+                raise ValueError("deliver needs a device `out` (and no eval count).")
+            if deliver.ndim != 2 or deliver.shape[0] != t.size or deliver.dtype != np.float64 \
+                    or deliver.strides[1] != 8 or deliver.shape[1] > n:
+                raise ValueError("deliver must be float64[levels, columns <= n], rows contiguous.")
+            self._check(self.lib.lbl_compute_streamed(
+                self.handle, int(molecule), t.size, t.ctypes.data, p.ctypes.data, x.ctypes.data,
+                int(v0), int(vn), int(n_per_v), int(cut_off), 1 if remove_pedestal else 0,
+                RANGE_POLICIES[range_policy], flags, pointer, 0, c_void_p(deliver.ctypes.data),
+                int(deliver.strides[0]) if t.size > 1 else max(int(deliver.strides[0]),
+                                                               8*deliver.shape[1]),
+                int(deliver.shape[1]), int(pieces)))
+            return out
         evals = c_int64(0)
         self._check(self.lib.lbl_compute(
             self.handle, int(molecule), t.size, t.ctypes.data, p.ctypes.data, x.ctypes.data,

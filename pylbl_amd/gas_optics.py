@@ -90,12 +90,14 @@ class Gas(object):
     def absorption_coefficients(self, temperature, pressure, volume_mixing_ratio, grid,
                                 remove_pedestal=False, cut_off=25, range_policy="reference",
                                 out=None, scale_density=False, accumulate=False,
-                                asynchronous=False, farfield=False):
+                                asynchronous=False, farfield=False, deliver=None, pieces=4):
         """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v].
 
         farfield: sum the lines far from each tile of the grid through one power series per tile
         (engine flag LBL_FARFIELD; truncation <= ~1.5e-11 relative, several times faster on fine
-        grids)."""
+        grids).
+        deliver: with a device `out`, a page-locked float64 [levels, columns] view that receives
+        the result while the call still computes, in `pieces` runs of tiles (Engine.compute)."""
         if self._deferred_error is not None:
             raise self._deferred_error
         v0, vn, n_per_v = grid_arguments(grid)
@@ -120,7 +122,8 @@ class Gas(object):
                                    v0, vn, n_per_v, cut_off=cut_off,
                                    remove_pedestal=remove_pedestal, range_policy=range_policy,
                                    out=out, scale_density=scale_density, accumulate=accumulate,
-                                   asynchronous=asynchronous, farfield=farfield)
+                                   asynchronous=asynchronous, farfield=farfield,
+                                   deliver=deliver, pieces=pieces)
 
     def __del__(self):
         try:

@@ -196,6 +196,8 @@ class Spectroscopy(object):
         self.gather_to = gather_to
         self.farfield = bool(farfield)
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
+        self.delivery_pieces = 4               # runs of tiles of the call that delivers its result
+        self.heaviest_first = False
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
         dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
@@ -281,11 +283,16 @@ class Spectroscopy(object):
         # Queue every kernel before waiting: one batched call per (molecule, mechanism) for
         # all levels, n*k applied in the kernel epilogue, spectra left in HBM until the end;
         # the sums over mechanisms ("gas") and over gases ("total") happen on the device.
+        # Within a block the short continuum and cross-section kernels go first and the lines
+        # last: the lines call that completes the LAST block of the whole call hands its result
+        # to the host itself, piece by piece while it computes (lbl_compute_streamed), so no
+        # copy is left standing behind the last kernel.
         blocks = {}             # (gas, mechanism) -> host array (only when too large for HBM)
         zero_fills = []         # row views of results that no mechanism writes
         results = {}            # gas -> its finished array, being filled by queued copies
         in_flight = []          # blocks in HBM to release once everything has arrived
         total = None
+        present = []
         for name in self.atmosphere.gases:
             data = self._molecule(name)
             gas = data.gas
@@ -301,7 +308,35 @@ class Spectroscopy(object):
             if engine is None:
                 engine = gas.engine if gas is not None else \
                     (continua_here[0].engine if continua_here else cross.engine)
-            if not in_hbm:
+            present.append((name, gas, continua_here, cross))
+        # The gas with the most transitions goes last: its lines call is the longest, and the
+        # one that can hand its block to the host while it computes; the blocks of the others
+        # travel beside the kernels of the gases behind them.  (Units are independent,
+        # spectroscopy.py:166,179; results are reported in the atmosphere's order.)
+        present.sort(key=lambda entry: entry[1].num_lines if entry[1] is not None else -1,
+                     reverse=self.heaviest_first)
+
+        def lines_into(name, gas, block, deliver=None):
+            gas.absorption_coefficients(
+                temperature, pressure, mole_fractions[name], self.grid,
+                remove_pedestal=remove_pedestal, range_policy=range_policy,
+                scale_density=True, out=block.buffer, accumulate=block.take(),
+                asynchronous=True, farfield=self.farfield, deliver=deliver,
+                pieces=self.delivery_pieces)
+
+        def slots_into(name, continua_here, cross, continuum_sum, cross_sum):
+            for continuum in continua_here:
+                continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
+                                         out=continuum_sum.buffer,
+                                         accumulate=continuum_sum.take(), asynchronous=True)
+            if cross is not None:
+                cross.absorption_coefficients(self.grid, temperature, pressure,
+                                              volume_mixing_ratio=mole_fractions[name],
+                                              out=cross_sum.buffer, accumulate=cross_sum.take(),
+                                              asynchronous=True)
+
+        if not in_hbm:
+            for name, gas, continua_here, cross in present:
                 # Too large to keep: one host block per mechanism, summed by numpy below.
                 if gas is not None:
                     blocks[(name, 0)] = gas.absorption_coefficients(
@@ -317,50 +352,68 @@ class Spectroscopy(object):
                     blocks[(name, 2)] = cross.absorption_coefficients(
                         self.grid, temperature, pressure,
                         volume_mixing_ratio=mole_fractions[name])
-                continue
-            if mode == "total":
-                if total is None:
-                    total = _Sum(engine, levels, n)
-                lines_sum = continuum_sum = cross_sum = total
-            elif mode == "gas":
-                lines_sum = continuum_sum = cross_sum = _Sum(engine, levels, n)
+        elif mode == "total" and present:
+            # Every gas adds into one block.  A gas's lines go first and its short continuum
+            # and cross-section kernels behind them (they run beside the next gas's lines, which
+            # work in buffers of their own until their last kernel) -- except for the gas that
+            # comes last: its lines call is the one that delivers, so it must be the last to add.
+            total = _Sum(engine, levels, n)
+            results["total"] = engine.host_array((levels, columns))
+            with_lines = [name for name, gas, _, _ in present if gas is not None]
+            for name, gas, continua_here, cross in present:
+                if with_lines and name == with_lines[-1]:
+                    continue
+                if gas is not None:
+                    lines_into(name, gas, total)
+                slots_into(name, continua_here, cross, total, total)
+            if with_lines:
+                name, gas, continua_here, cross = [x for x in present if x[0] == with_lines[-1]][0]
+                slots_into(name, continua_here, cross, total, total)
+                lines_into(name, gas, total, deliver=results["total"])
+                in_flight.append(total)
             else:
-                cross_sum = _Sum(engine, levels, n) if cross is not None else None
-                lines_sum = _Sum(engine, levels, n) if gas is not None else None
-                continuum_sum = _Sum(engine, levels, n) if continua_here else None
-            if gas is not None:
-                gas.absorption_coefficients(
-                    temperature, pressure, mole_fractions[name], self.grid,
-                    remove_pedestal=remove_pedestal, range_policy=range_policy,
-                    scale_density=True, out=lines_sum.buffer, accumulate=lines_sum.take(),
-                    asynchronous=True, farfield=self.farfield)
-            for continuum in continua_here:
-                continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
-                                         out=continuum_sum.buffer,
-                                         accumulate=continuum_sum.take(), asynchronous=True)
-            if cross is not None:
-                cross.absorption_coefficients(self.grid, temperature, pressure,
-                                              volume_mixing_ratio=mole_fractions[name],
-                                              out=cross_sum.buffer, accumulate=cross_sum.take(),
-                                              asynchronous=True)
-            # This gas's blocks go home while the next gas computes: one copy per block, from
-            # HBM straight into its place in a page-locked result.
-            if mode == "all":
+                in_flight.append(total.into(results["total"]))
+        else:
+            for index, (name, gas, continua_here, cross) in enumerate(present):
+                last = index + 1 == len(present)
+                if mode == "gas":
+                    block = _Sum(engine, levels, n)
+                    results[name] = engine.host_array((levels, columns))
+                    if gas is not None and last:
+                        slots_into(name, continua_here, cross, block, block)
+                        lines_into(name, gas, block, deliver=results[name])
+                        in_flight.append(block)
+                    else:
+                        if gas is not None:
+                            lines_into(name, gas, block)
+                        slots_into(name, continua_here, cross, block, block)
+                        # This gas's block goes home while the next gas computes: one copy,
+                        # from HBM straight into its place in a page-locked result.
+                        in_flight.append(block.into(results[name]))
+                    continue
                 values = engine.host_array([levels, len(MECHANISMS), columns])
-                for slot, block in enumerate((lines_sum, continuum_sum, cross_sum)):
+                results[name] = values
+                continuum_sum = _Sum(engine, levels, n) if continua_here else None
+                cross_sum = _Sum(engine, levels, n) if cross is not None else None
+                if continua_here or cross is not None:
+                    slots_into(name, continua_here, cross, continuum_sum, cross_sum)
+                for slot, block in ((1, continuum_sum), (2, cross_sum)):
                     if block is None:
                         # An empty mechanism slot reads zero (40 MB per level at 5 M points):
                         # filled by a helper thread beside the queueing and the kernels.
                         zero_fills.append(values[:, slot, :])
                     else:
                         in_flight.append(block.into(values[:, slot, :]))
-                results[name] = values
-            elif mode == "gas":
-                results[name] = engine.host_array((levels, columns))
-                in_flight.append(lines_sum.into(results[name]))
-        if mode == "total" and total is not None:
-            results["total"] = engine.host_array((levels, columns))
-            in_flight.append(total.into(results["total"]))
+                if gas is None:
+                    zero_fills.append(values[:, 0, :])
+                else:
+                    lines_sum = _Sum(engine, levels, n)
+                    if last:
+                        lines_into(name, gas, lines_sum, deliver=values[:, 0, :])
+                        in_flight.append(lines_sum)
+                    else:
+                        lines_into(name, gas, lines_sum)
+                        in_flight.append(lines_sum.into(values[:, 0, :]))
         filler = _zero_in_background(zero_fills)
         if engine is not None:
             engine.synchronize()

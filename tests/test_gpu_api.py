@@ -523,6 +523,63 @@ def test_molecule_without_lines_adds_nothing_and_stays_ordered():
     e.close()
 
 
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+@pytest.mark.parametrize("farfield", [False, True])
+def test_streamed_call_delivers_what_the_plain_call_computes(remove_pedestal, farfield):
+    """lbl_compute_streamed: the grid in 1..8 runs of tiles, each run's columns copied to
+    page-locked host memory beside the next run's kernels.  Same kernels, same order of
+    additions: the block in HBM and the delivered array equal the plain call bit for bit --
+    several levels, level passes forced by a small workspace, fewer columns than points (what
+    Spectroscopy asks for), a pitched target, and adding into a block that holds something."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CO2", 1., 260., num_lines=40000, seed=5, tips_range=(150, 400))
+    banded = synthetic.banded_line_table("H2O", 1., 260., num_lines=30000, bands=3, seed=6)
+    atmos = synthetic.standard_atmosphere(5)
+    v0, vn, npv = 1, 241, 1000
+    n = (vn - v0)*npv
+    columns = n - 1000
+    for t, formula in ((table, "CO2"), (banded, "H2O")):
+        h = e.load(t)
+        x = atmos.vmr[formula]
+        plain = DeviceSpectra(e, 5, n)
+        e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal,
+                  out=plain, scale_density=True, farfield=farfield)
+        expect = plain.to_host()
+        for pieces in (1, 3, 4, 8):
+            out = DeviceSpectra(e, 5, n)
+            holder = e.host_array((5, 3, columns))
+            holder[...] = -1.
+            target = holder[:, 1, :]                        # pitched: rows 3*columns apart
+            e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal,
+                      out=out, scale_density=True, farfield=farfield, asynchronous=True,
+                      deliver=target, pieces=pieces)
+            e.synchronize()
+            assert np.array_equal(target, expect[:, :columns]), (formula, pieces)
+            assert np.all(holder[:, 0, :] == -1.) and np.all(holder[:, 2, :] == -1.)
+            assert np.array_equal(out.to_host(), expect), (formula, pieces)
+            out.free()
+        # level passes (workspace for ~2 levels) and adding into a block that holds something
+        e.set_option("workspace_bytes", 96 << 20)
+        out = DeviceSpectra(e, 5, n)
+        e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal, out=out,
+                  scale_density=True, farfield=farfield)
+        target = e.host_array((5, columns))
+        e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal, out=out,
+                  scale_density=True, farfield=farfield, accumulate=True, asynchronous=True,
+                  deliver=target, pieces=4)
+        e.synchronize()
+        e.set_option("workspace_bytes", 4 << 30)
+        assert np.array_equal(out.to_host()[:, :columns], target)
+        assert np.max(np.abs(target - 2.*expect[:, :columns])) <= 1e-15*np.max(expect)
+        out.free()
+        plain.free()
+        e.free(h)
+    with pytest.raises(ValueError):
+        e.compute(1, 250., 1e4, 1e-3, 1, 50, 10, deliver=np.zeros((1, 490)))   # host `out`
+    e.close()
+
+
 def test_compat_entry_device_and_cache(tmp_path):
     """The same-signature entry picks its GPU from LBL_DEVICE / the launcher's local rank,
     re-reads a database file that changed under the same path (the reference re-reads it on
