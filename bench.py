@@ -266,10 +266,14 @@ def profiled_traffic(workload, kernel="accumulate_kernel"):
                 continue
             for name, counters in summary["counters"].items():
                 if kernel in name and "hbm_bytes_per_launch" in counters:
+                    PROFILED_RAW[kernel] = counters.get("hbm_bytes_per_launch_uncorrected")
                     return counters["hbm_bytes_per_launch"], os.path.basename(path)
         except (OSError, KeyError, TypeError, ValueError):
             continue
     return None, None
+
+
+PROFILED_RAW = {}       # kernel -> FETCH_SIZE + WRITE_SIZE as counted (no gfx950 read correction)
 
 
 def profiled_issue(workload):
@@ -880,6 +884,12 @@ def run():
         if traffic is not None:
             line["roofline"]["traffic"] = traffic
             line["roofline"]["traffic_source"] = f"profiles/{source}"
+            line["roofline"]["traffic_uncorrected"] = PROFILED_RAW.get("accumulate_kernel")
+            line["roofline"]["traffic_note"] = (
+                "traffic = WRITE_SIZE + 2 x FETCH_SIZE (the gfx950 correction for wide coalesced "
+                "reads); this kernel reads its line records through scalar loads, for which the "
+                "uncorrected count (traffic_uncorrected = WRITE_SIZE + FETCH_SIZE) may be the truer "
+                "one -- either way 0.3-0.7 TB/s, a tenth of the HBM roofline")
         issue = profiled_issue(workload)
         if issue is not None and issue.get("evals_per_launch"):
             per_eval = issue["fp64_wave_instructions_per_launch"]*64./issue["evals_per_launch"]

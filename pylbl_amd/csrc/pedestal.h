@@ -429,6 +429,58 @@ __device__ __forceinline__ double shuffle_up(double value, int offset)
     return __shfl_up(value, offset, 64);
 }
 
+// Lane-to-lane moves by data-parallel primitives (DPP): the operand of a VALU instruction is
+// taken from another lane of the row of 16 (row_shr:n), from the last lane of the previous row
+// (row_bcast:15, rows 1 and 3) or from lane 31 (row_bcast:31, rows 2 and 3) -- a few cycles,
+// where a shuffle through the LDS crossbar (ds_bpermute) is a round trip of ~100.  The chain
+// below is one wavefront whose every step waits for the previous one: its scans are the serial
+// path of the whole pedestal pass.  Lanes without a source keep `fill`.
+template <int CONTROL, int ROWS>
+__device__ __forceinline__ double dpp_from(double fill, double value)
+{
+    const long long f = __double_as_longlong(fill), v = __double_as_longlong(value);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)v, CONTROL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(v >> 32), CONTROL, ROWS, 0xf,
+                                               false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+
+// Inclusive prefix sums over the 64 lanes (Kogge-Stone inside the rows, then the row totals).
+__device__ __forceinline__ double wave_prefix_sum(double x)
+{
+    x += dpp_from<kRowShr1, 0xf>(0., x);
+    x += dpp_from<kRowShr2, 0xf>(0., x);
+    x += dpp_from<kRowShr4, 0xf>(0., x);
+    x += dpp_from<kRowShr8, 0xf>(0., x);
+    x += dpp_from<kRowBcast15, 0xa>(0., x);
+    x += dpp_from<kRowBcast31, 0xc>(0., x);
+    return x;
+}
+
+// Inclusive scan over lanes 0..31 of the composition of L -> min(L + a, c): the element (a, c)
+// of a lane becomes (sum of the a's up to it, the smallest c_i + (a's after i)).  Lanes 32..63
+// must hold the identity (0, inf); they are left undefined.
+__device__ __forceinline__ void half_wave_min_plus_scan(double & a, double & c)
+{
+    const double inf = __builtin_inf();
+#define LBL_MIN_PLUS_STEP(CONTROL, ROWS)                                   \
+    {                                                                       \
+        const double a_left = dpp_from<CONTROL, ROWS>(0., a);               \
+        const double c_left = dpp_from<CONTROL, ROWS>(inf, c);              \
+        c = fmin(c_left + a, c);                                            \
+        a = a_left + a;                                                     \
+    }
+    LBL_MIN_PLUS_STEP(kRowShr1, 0xf)
+    LBL_MIN_PLUS_STEP(kRowShr2, 0xf)
+    LBL_MIN_PLUS_STEP(kRowShr4, 0xf)
+    LBL_MIN_PLUS_STEP(kRowShr8, 0xf)
+    LBL_MIN_PLUS_STEP(kRowBcast15, 0xa)
+#undef LBL_MIN_PLUS_STEP
+}
+
 constexpr int kScanBlock = 32;      // runs per (min,+) scan
 constexpr int kLinkChunk = 256;     // run links staged in LDS at a time
 
@@ -498,12 +550,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
         const bool contiguous = ((old_s & (old_s + 1ull)) | (old_e & (old_e + 1ull))) == 0ull;
         if (__ballot(!contiguous) == 0ull)
         {
-            double prefix = entry;
-            for (int offset = 1; offset < 64; offset <<= 1)
-            {
-                const double up = shuffle_up(prefix, offset);
-                if (lane >= offset) prefix += up;
-            }
+            const double prefix = wave_prefix_sum(entry);
             const int count_s = __builtin_popcountll(old_s), count_e = __builtin_popcountll(old_e);
             const double at_s = __shfl(prefix, (count_s - 1) & 63, 64);
             const double at_e = __shfl(prefix, (count_e - 1) & 63, 64);
@@ -545,16 +592,8 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
             }
         }
         const double a_own = a, c_own = c;
-        for (int offset = 1; offset < kScanBlock; offset <<= 1)
-        {
-            const double a_left = shuffle_up(a, offset);
-            const double c_left = shuffle_up(c, offset);
-            if (lane >= offset)
-            {
-                c = fmin(c_left + a, c);
-                a = a_left + a;
-            }
-        }
+        static_assert(kScanBlock == 32, "half_wave_min_plus_scan covers lanes 0..31");
+        half_wave_min_plus_scan(a, c);
         const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
         double before = shuffle_up(total, 1);
         if (lane == 0) before = 0.;
