@@ -120,6 +120,7 @@ struct AccumulateArgs
     double dv;
     int scale_density;
     int accumulate;
+    int inner_everywhere;           // 0: only the core-range lines can have inner points in a tile
     int ablate;                     // diagnostics only: 1 skips the general ranges, 2 the fast ranges
 };
 
@@ -174,17 +175,17 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 // Per row the decisions are wave-uniform: skip (outside the window), Lorentz (whole row in
 // the far wing), or core.  In a core row every lane applies the reference's chain on
 // xi = (v-nu')*repwid (voigt.c:76-84): region 0 and w4 region 1 (voigt.c:95-96) are
-// evaluated inline.  Lanes closer to the centre than xlim1 add nothing here: the function
-// reports whether the tile may hold such points, and general_ranges() sums the inner points of
-// a whole batch of lines afterwards (inner_batch), into the wavefront's LDS sums.
+// evaluated inline.  Lanes closer to the centre than xlim1 add nothing here: the inner points of
+// all the lines walked here are summed afterwards, in a pass of their own (inner_ranges), into
+// the wavefront's LDS sums.
 template <int P>
-__device__ __forceinline__ bool general_line(const LineWing & l, const LineCore & c,
+__device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
                                              int i0, int i1, int lane,
                                              const double (&v)[P], double (&acc)[P])
 {
     if (l.last < i0 || l.first > i1)
     {
-        return false;     // also skips empty windows
+        return;     // also skips empty windows
     }
     const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
     const double yq = c.y*c.y;
@@ -192,7 +193,6 @@ __device__ __forceinline__ bool general_line(const LineWing & l, const LineCore 
     const double d0 = a0*a0;
     const double d2 = yq + yq - 1.;
     const double r1_scale = c.amp*rsqrpi*c.y;
-    bool core_row = false;
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
@@ -213,7 +213,6 @@ __device__ __forceinline__ bool general_line(const LineWing & l, const LineCore 
         }
         else
         {
-            core_row = true;
             const double xi = d*c.repwid;               // voigt.c:76
             const double abx = fabs(xi);
             const double xq = abx*abx;
@@ -235,8 +234,6 @@ __device__ __forceinline__ bool general_line(const LineWing & l, const LineCore 
         }
         acc[p] += inside ? value : 0.;
     }
-    // May the tile hold inner points of this line?  (xlim1 == 0: the line has none at all.)
-    return core_row && c.xlim1 > 0.;
 }
 
 // Up to five index ranges of lines in general position, walked as one list; records are
@@ -277,12 +274,11 @@ __device__ __forceinline__ int general_index(const GeneralList & g, int k)
 //                         wavefront, index = point - tile_first) one line at a time: two lines of
 //                         a list may cover the same grid point, and the order of additions is
 //                         fixed -- results do not depend on scheduling.
-constexpr int kInnerQueue = 32;         // lines per batch
+constexpr int kInnerQueue = 32;         // lines per batch (lane = line in step 1)
 constexpr int kInnerList = 128;         // entries a class list can hold (64 left + 64 new)
 
 struct InnerStage
 {
-    int line[kInnerQueue];              // the queue: lines of the batch with a core row in the tile
     int first[kInnerQueue];             // first inner point in tile and window
     int begin[kInnerQueue], end[kInnerQueue];   // the line's segment in the packed sequence
     double centre[kInnerQueue], repwid[kInnerQueue], y[kInnerQueue], amp[kInnerQueue];
@@ -322,26 +318,41 @@ __device__ __forceinline__ void inner_evaluate(InnerStage & stage, int count, in
     }
 }
 
-__device__ __forceinline__ void inner_batch(const LineWing * __restrict__ wing,
+// `j` is this lane's line of the batch (lanes >= kInnerQueue and lanes beyond the batch: has =
+// false).  Returns without touching LDS when no line of the batch has an inner point in the tile:
+// the common case at tropospheric pressure, where y >= 8.425 switches the inner regions off for
+// most lines, and for the lines of a batch whose cores lie in other tiles.
+__device__ __forceinline__ bool inner_batch(const LineWing * __restrict__ wing,
                                             const LineCore * __restrict__ core,
-                                            InnerStage & stage, int queued, int i0, int i1,
+                                            InnerStage & stage, int j, bool has, int i0, int i1,
                                             int v0, int n_per_v, double dv, int lane,
-                                            double * slab)
+                                            double * slab, bool slab_in_use, int slab_rows)
 {
     // Step 1.
     unsigned long long todo;
     int total;
     {
-        const bool has = lane < queued;
-        const int j = stage.line[has ? lane : 0];
-        const double centre = wing[j].centre;
-        const int window_first = wing[j].first, window_last = wing[j].last;
-        const double repwid = core[j].repwid, xlim1 = core[j].xlim1;
-        int first, last;
-        inner_index_range(centre, repwid, xlim1, v0, n_per_v, first, last);
-        first = max(max(first, window_first), i0);
-        last = min(min(last, window_last), i1);
-        const int length = (has && last >= first) ? last - first + 1 : 0;
+        const LineWing l = wing[j];
+        const LineCore c = core[j];
+        int first = 0, last = -1;
+        if (has && c.xlim1 > 0. && c.core_last >= i0 && c.core_first <= i1)
+        {
+            inner_index_range(l.centre, c.repwid, c.xlim1, v0, n_per_v, first, last);
+            first = max(max(first, l.first), i0);
+            last = min(min(last, l.last), i1);
+        }
+        const int length = last >= first ? last - first + 1 : 0;
+        todo = __ballot(length > 0);
+        if (todo == 0)
+        {
+            return false;
+        }
+        if (!slab_in_use)
+        {
+            // The wavefront's LDS sums are cleared by the first batch that has something to add
+            // (most tiles at tropospheric pressure never get here).
+            for (int p = 0; p < slab_rows; ++p) slab[p*64 + lane] = 0.;
+        }
         int inclusive = length;
 #pragma unroll
         for (int offset = 1; offset < kInnerQueue; offset <<= 1)
@@ -354,14 +365,13 @@ __device__ __forceinline__ void inner_batch(const LineWing * __restrict__ wing,
             stage.first[lane] = first;
             stage.begin[lane] = inclusive - length;
             stage.end[lane] = inclusive;
-            stage.centre[lane] = centre;
-            stage.repwid[lane] = repwid;
-            stage.y[lane] = core[j].y;
-            stage.amp[lane] = core[j].amp;
-            stage.xlim1[lane] = xlim1;
+            stage.centre[lane] = l.centre;
+            stage.repwid[lane] = c.repwid;
+            stage.y[lane] = c.y;
+            stage.amp[lane] = c.amp;
+            stage.xlim1[lane] = c.xlim1;
         }
         total = __builtin_amdgcn_readlane(inclusive, kInnerQueue - 1);
-        todo = __ballot(length > 0);
     }
 
     int count[kInnerClasses] = {0, 0, 0};
@@ -440,58 +450,64 @@ __device__ __forceinline__ void inner_batch(const LineWing * __restrict__ wing,
             break;
         }
     }
+    return true;
 }
 
-// Lines are walked in batches: first the rows of every line of the batch (registers), noting
-// in `stage.line` (LDS, this wavefront's) which lines may have inner points in the tile,
-// then those points in one place (inner_batch) -- the two halves need different registers, and
-// kept apart neither pays for the other's.
 template <int P>
 __device__ __forceinline__ void general_ranges(const LineWing * __restrict__ wing,
                                                const LineCore * __restrict__ core,
                                                const GeneralList & g, int i0, int i1, int lane,
-                                               int v0, int n_per_v, double dv,
-                                               const double (&v)[P], double (&acc)[P],
-                                               double * slab, InnerStage & stage, int ablate = 0)
+                                               const double (&v)[P], double (&acc)[P])
 {
     const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
     int k = 0;
-    while (k < total)
+    for (; k + 2 <= total; k += 2)
     {
-        int queued = 0;
-        for (; k + 2 <= total && queued + 2 <= kInnerQueue; k += 2)
-        {
-            const int ja = general_index(g, k), jb = general_index(g, k + 1);
-            const LineWing la = wing[ja], lb = wing[jb];
-            const LineCore ca = core[ja], cb = core[jb];
-            if (general_line<P>(la, ca, i0, i1, lane, v, acc))
-            {
-                if (lane == 0) stage.line[queued] = ja;
-                ++queued;
-            }
-            if (general_line<P>(lb, cb, i0, i1, lane, v, acc))
-            {
-                if (lane == 0) stage.line[queued] = jb;
-                ++queued;
-            }
-        }
-        if (k + 1 == total && queued < kInnerQueue)
-        {
-            const int ja = general_index(g, k);
-            const LineWing la = wing[ja];
-            const LineCore ca = core[ja];
-            if (general_line<P>(la, ca, i0, i1, lane, v, acc))
-            {
-                if (lane == 0) stage.line[queued] = ja;
-                ++queued;
-            }
-            ++k;
-        }
-        if (queued > 0 && !(ablate & 32))       // (32: diagnostics, leaves the inner points out)
-        {
-            inner_batch(wing, core, stage, queued, i0, i1, v0, n_per_v, dv, lane, slab);
-        }
+        const int ja = general_index(g, k), jb = general_index(g, k + 1);
+        const LineWing la = wing[ja], lb = wing[jb];
+        const LineCore ca = core[ja], cb = core[jb];
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
+        general_line<P>(lb, cb, i0, i1, lane, v, acc);
     }
+    if (k < total)
+    {
+        const int ja = general_index(g, k);
+        const LineWing la = wing[ja];
+        const LineCore ca = core[ja];
+        general_line<P>(la, ca, i0, i1, lane, v, acc);
+    }
+}
+
+// The second pass over the lines of the general list, kInnerQueue at a time with lane = line
+// (their records arrive by one coalesced gather): the inner points the rows left out.  Kept
+// apart from the walk above on purpose -- the two need different registers, and as one loop each
+// paid for the other's (53 spilled SGPRs against 26, 1-6 % on workloads that have no inner point
+// to evaluate).
+__device__ __forceinline__ bool inner_ranges(const LineWing * __restrict__ wing,
+                                             const LineCore * __restrict__ core,
+                                             const GeneralList & g, InnerStage & stage,
+                                             int i0, int i1, int v0, int n_per_v, double dv,
+                                             int lane, double * slab, int slab_rows)
+{
+    bool used = false;
+    const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
+    for (int base = 0; base < total; base += kInnerQueue)
+    {
+        const int k = base + lane;
+        const bool has = lane < kInnerQueue && k < total;
+        // general_index() lane by lane.
+        int j = g.begin[0], rest = has ? k : 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+        {
+            const bool here = rest >= 0 && rest < g.count[r];
+            j = here ? g.begin[r] + rest : j;
+            rest = here ? -1 : rest - g.count[r];
+        }
+        used |= inner_batch(wing, core, stage, j, has, i0, i1, v0, n_per_v, dv, lane, slab, used,
+                            slab_rows);
+    }
+    return used;
 }
 
 // Contiguous share `part` of `parts` of the index range [j0, j1), in units of `unit` lines
@@ -510,8 +526,7 @@ __device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, in
 // four partial sums meet in LDS and each wavefront finishes P/4 of the rows (scaling, the
 // one store of k -- or of the item's partial sums when the tile was split).
 template <int P>
-__global__ __launch_bounds__(256)
-void accumulate_kernel(const AccumulateArgs a)
+__device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
 {
     __shared__ double partial[4][P][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -527,8 +542,8 @@ void accumulate_kernel(const AccumulateArgs a)
     const LineCore * __restrict__ core = a.core + (long long)level*a.n_lines;
 
     double v[P], acc[P];
-    // This wavefront's block of the LDS sums: what inner_pass() adds to while the lines are
-    // walked, and where the register sums join it at the end.
+    // This wavefront's block of the LDS sums: what the inner pass adds to, and where the
+    // register sums join it at the end.
     double * slab = &partial[wave][0][0];
     __shared__ InnerStage inner_stage[4];
 #pragma unroll
@@ -539,7 +554,6 @@ void accumulate_kernel(const AccumulateArgs a)
         const double step = (double)i*a.dv;
         v[p] = (double)a.v0 + step;
         acc[p] = 0.;
-        partial[wave][p][lane] = 0.;
     }
 
     // This wavefront's share of each of the five cut-point ranges: the item's part of the
@@ -568,16 +582,29 @@ void accumulate_kernel(const AccumulateArgs a)
     {
         fast_ranges<P>(wing, fa0, fa1, fb0, fb1, v, acc);
     }
+    bool slab_in_use = false;
     if (!(a.ablate & 1))
     {
-        general_ranges<P>(wing, core, g, i0, i1, lane, a.v0, a.n_per_v, a.dv, v, acc, slab,
-                          inner_stage[wave], a.ablate);
+        general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
+        if (!(a.ablate & 32))       // (32: diagnostics, leaves the inner points out)
+        {
+            // With the reference's cut-off of 25 cm-1 a line whose window clips the tile, or
+            // whose wing covers it, is far from having its core there: only the core-range
+            // lines need the second look.  (Cut-offs of a wavenumber or two: everything.)
+            GeneralList inner = g;
+            if (!a.inner_everywhere)
+            {
+                inner.count[0] = inner.count[2] = inner.count[3] = inner.count[4] = 0;
+            }
+            slab_in_use = inner_ranges(wing, core, inner, inner_stage[wave], i0, i1, a.v0,
+                                       a.n_per_v, a.dv, lane, slab, P);
+        }
     }
 
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
-        partial[wave][p][lane] += acc[p];
+        partial[wave][p][lane] = slab_in_use ? partial[wave][p][lane] + acc[p] : acc[p];
     }
     __syncthreads();
 
@@ -643,6 +670,24 @@ void accumulate_kernel(const AccumulateArgs a)
             out[i] = value;
         }
     }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
+{
+    accumulate_tile<P>(a);
+}
+
+// The eight-points-per-lane form (far-field series on: few lines per tile are evaluated point by
+// point, so the tile is made wide) with an occupancy hint.  Left alone the scheduler spends 108
+// VGPRs on it (4 wavefronts per SIMD); told that occupancy matters it makes do with 78, and the
+// far-field step gains 10-11 % (profiles/r03_ab_occupancy.txt).  The same hint on P <= 4 buys
+// nothing (71 instead of 75 VGPRs, +-0 to -1 %), so those are left to the compiler.
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+void accumulate_kernel<8>(const AccumulateArgs a)
+{
+    accumulate_tile<8>(a);
 }
 
 // Adds up the partial sums of the split tiles, part 0 first (fixed order), and writes k.

@@ -1048,6 +1048,21 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             // With a pedestal the kernel stores plain sums; pedestal_apply_kernel finishes.
             args.scale_density = (!with_pedestal && (rq.flags & LBL_SCALE_DENSITY)) ? 1 : 0;
             args.accumulate = (!with_pedestal && out_device && add_into) ? 1 : 0;
+            // Can a line outside a tile's core range have its core in the tile?  Only if the
+            // window (cut_off + 1 on either side) is not much wider than a core can reach
+            // (schedule_tile: core_reach x wavenumber, + the widest pressure shift) plus a tile.
+            {
+                double reach = 0.;
+                for (int l = 0; l < count; ++l)
+                {
+                    const LevelScalars & lv = lane.pinned_levels[l];
+                    const double kk = lv.core_reach;
+                    reach = std::max(reach, kk < 0.5 ? kk*(rq.vn + 1.)/(1. - kk) + 2.*lv.shift_max
+                                                     : 1.e9);
+                }
+                const double tile_width = (double)tiling.length*g.dv;
+                args.inner_everywhere = (rq.cut_off - 1. <= reach + tile_width + 1.) ? 1 : 0;
+            }
             args.ablate = engine->ablate;
 
             if (with_pedestal && engine->overlap_pedestal && engine->order_runs)

@@ -482,7 +482,11 @@ __device__ __forceinline__ void half_wave_min_plus_scan(double & a, double & c)
 }
 
 constexpr int kScanBlock = 32;      // runs per (min,+) scan
-constexpr int kLinkChunk = 256;     // run links staged in LDS at a time
+// (The chain kernels are single workgroups that start beside a resident accumulate grid, whose
+// workgroups hold 12-27 KB of LDS each, six or seven to a CU: what a chain kernel asks for must
+// fit in what they leave, ~50 KB, or it waits for a CU to drain -- 1.4 ms in a kernel trace when
+// the fallback below asked for 108 KB only to find nothing to do.)
+constexpr int kLinkChunk = 128;     // run links staged in LDS at a time
 
 // One wavefront per level; only acts on levels run_links_kernel left flagged regular.
 __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restrict__ run_count,
@@ -947,9 +951,14 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
                            ws.bin_sum.data);
         check(hipGetLastError(), "run_chain_scan_kernel");
     }
+    // The serial chain takes the levels the scan left (flag `regular` cleared; with an ascending
+    // table: none, or the few whose windows are crowded with more runs than the scan's masks
+    // reach).  Behind a scan it is launched in its small-LDS form (slots of the spectrum in HBM,
+    // the active ones in registers): it usually only looks at the flags and returns, and must
+    // not queue for most of a CU's LDS to do that.
     const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
     const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
-    if (lds_bytes <= 160*1024 - 512)
+    if (lds_bytes <= 160*1024 - 512 && !try_scan)
     {
         if (lds_bytes > 64*1024)
         {
