@@ -672,7 +672,10 @@ def run():
                 out.append(uniform)
         return out
     tables = make_tables(args.banded)
-    engine = Engine(device_index)
+    # The process-wide engine of the device: the one Spectroscopy / Gas objects use too (api leg),
+    # so that the process has one set of streams.
+    from pylbl_amd.engine import default_engine
+    engine = default_engine(device_index)
     if args.points_per_lane:
         engine.set_option("points_per_lane", args.points_per_lane)
     for pair in args.engine_option:
