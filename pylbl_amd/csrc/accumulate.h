@@ -332,10 +332,19 @@ __device__ __forceinline__ bool inner_batch(const LineWing * __restrict__ wing,
     unsigned long long todo;
     int total;
     {
+        // Two fields decide for most lines (xlim1 == 0: no inner regions at all; core range
+        // elsewhere): the rest of the record is fetched only if some line of the batch passes.
+        const double xlim1 = core[j].xlim1;
+        const bool candidate = has && xlim1 > 0. && core[j].core_last >= i0 &&
+                               core[j].core_first <= i1;
+        if (__ballot(candidate) == 0)
+        {
+            return false;
+        }
         const LineWing l = wing[j];
         const LineCore c = core[j];
         int first = 0, last = -1;
-        if (has && c.xlim1 > 0. && c.core_last >= i0 && c.core_first <= i1)
+        if (candidate)
         {
             inner_index_range(l.centre, c.repwid, c.xlim1, v0, n_per_v, first, last);
             first = max(max(first, l.first), i0);
@@ -586,7 +595,9 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     if (!(a.ablate & 1))
     {
         general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
-        if (!(a.ablate & 32))       // (32: diagnostics, leaves the inner points out)
+        // (32: diagnostics, leaves the inner points out.)  Levels at which no line of the call
+        // can have an inner point -- the host's bound on y, engine.hip -- skip the look.
+        if (!(a.ablate & 32) && a.levels[level].inner_possible != 0.)
         {
             // With the reference's cut-off of 25 cm-1 a line whose window clips the tile, or
             // whose wing covers it, is far from having its core there: only the core-range

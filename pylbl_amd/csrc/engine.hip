@@ -104,6 +104,8 @@ struct Molecule
     struct BadRow { int row; double nu; int local_iso_id; };
     std::vector<BadRow> bad_rows;
     double max_abs_delta = 0.;
+    // Extremes over the table's rows, for the bound on y below which a level can have inner points.
+    double min_gamma_air = 1.e300, min_gamma_self = 1.e300, min_n_air = 1.e300, max_n_air = -1.e300;
     int num_iso = 0, num_t = 0;
     std::vector<double> tips_t, tips_q;
     // Device copies (sorted).
@@ -903,11 +905,39 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             for (int l = 0; l < count; ++l)
             {
                 std::string why;
+                LevelScalars & lv = lane.pinned_levels[l];
                 if (!fill_level(*m, rq.temperature[base + l], rq.pressure[base + l],
-                                rq.vmr[base + l], lane.pinned_levels[l], why))
+                                rq.vmr[base + l], lv, why))
                 {
                     return fail(engine, LBL_OUT_OF_RANGE,
                                 "level " + std::to_string(base + l) + ": " + why);
+                }
+                // Can any accepted line have y < 8.425 at this level (voigt.c:35-43: below that
+                // the inner regions exist)?  y = sqrt(ln2) gamma/alpha with gamma >= the
+                // smallest half-widths of the table at this pressure (spectra.c:25-26) and alpha
+                // <= the widest Doppler width at the largest accepted wavenumber (spectra.c:29,
+                // absorption.c:80-83).  The accumulate kernel skips its look for inner points at
+                // levels where the answer is no: all of a CO2 table at 1 atm, for instance.
+                lv.inner_possible = 1.;
+                const double foreign = lv.p_atm - lv.p_partial;
+                if (foreign >= 0. && lv.p_partial >= 0. && m->min_gamma_air >= 0. &&
+                    m->min_gamma_self >= 0. && m->n_lines > 0)
+                {
+                    double widest = 0.;
+                    for (int slot = 0; slot < kMassSlots; ++slot)
+                    {
+                        widest = std::max(widest, lv.doppler[slot]);
+                    }
+                    const double power = std::min(pow(lv.tfact, m->min_n_air),
+                                                  pow(lv.tfact, m->max_n_air));
+                    const double gamma = (m->min_gamma_air*foreign +
+                                          m->min_gamma_self*lv.p_partial)*power;
+                    const double alpha = (rule.nu_max/2.99792458e8)*widest;
+                    const double y_lower = sqrt(log(2.))*gamma/alpha*(1. - 1.e-9);
+                    if (alpha > 0. && y_lower >= 8.425)
+                    {
+                        lv.inner_possible = 0.;
+                    }
                 }
             }
             // A few levels travel as kernel arguments of the prologue kernel (no copy in front
@@ -1410,6 +1440,10 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
             m->iso_slot[j] = slot;
             m->used_slots |= 1u << slot;
             m->max_abs_delta = std::max(m->max_abs_delta, fabs(m->column[6][j]));
+            m->min_gamma_air = std::min(m->min_gamma_air, m->column[2][j]);
+            m->min_gamma_self = std::min(m->min_gamma_self, m->column[3][j]);
+            m->min_n_air = std::min(m->min_n_air, m->column[4][j]);
+            m->max_n_air = std::max(m->max_n_air, m->column[4][j]);
         }
         hipStream_t stream = engine->stream;
         for (int c = 0; c < 7; ++c) m->d_column[c].upload(m->column[c].data(), n_lines, stream);

@@ -33,6 +33,8 @@ struct LevelScalars
     double shift_max;       // bound on |p*delta_air| over the table (+ margin)
     double core_reach;      // bound on (far-wing limit / repwid) / nu over the table
     double density;         // P x /(kb T)                       spectroscopy.py:18-29
+    double inner_possible;  // 0: y >= 8.425 for every line of this call at this level, i.e. no line
+                            // has points in the inner regions (voigt.c:35-43); else 1
     double doppler[kMassSlots];   // sqrt(2 ln2 * 8314.472 * T / mass[iso])   spectra.c:29
     double q_ratio[kMassSlots];   // Q(296)/Q(T) per isotopologue             spectra.c:41-42
 };
