@@ -236,6 +236,82 @@ def test_other_cut_offs(engine, oracle, cut_off):
     engine.free(molecule)
 
 
+@pytest.mark.parametrize("cut_off", [0, 1, 2, 3, 25])
+@pytest.mark.parametrize("npv", [1000, 250])
+def test_inner_points_of_lines_in_every_range(engine, oracle, cut_off, npv):
+    """The points nearer to a line centre than xlim1 (w4 regions 2-3, CPF12) are summed by a pass
+    of their own that normally looks at the core-range lines of a tile only; with a cut-off of a
+    wavenumber or two a line whose window clips the tile can have its core there, and the pass has
+    to take every range (accumulate.h: inner_everywhere).  Dense narrow lines at stratospheric
+    pressures, fine grids, every small cut-off, all tile sizes, far-field series on and off."""
+    from pylbl_amd import synthetic
+    # every row inside v0 - 1 ... vn + 1, so that the reference's range `break` (absorption.c:80-83)
+    # discards nothing at any cut-off
+    table = synthetic.line_table("H2O", 2005.2, 2024.8, num_lines=4000, seed=123,
+                                 tips_range=(150, 400))
+    levels = np.asarray([[220., 1000., 4e-6], [250., 100., 5e-6], [200., 10., 3e-6],
+                         [288.99, 98388., 6.6e-3]])
+    v0, vn = 2005, 2025
+    molecule = engine.load(table)
+    try:
+        for points, farfield in ((0, 0), (1, 0), (2, 0), (8, 1), (4, 1)):
+            engine.set_option("points_per_lane", points)
+            engine.set_option("farfield", farfield)
+            for ped in (False, True):
+                k = engine.compute(molecule, levels[:, 0], levels[:, 1], levels[:, 2], v0, vn, npv,
+                                   cut_off=cut_off, remove_pedestal=ped)
+                case = golden_io.Case("inner", 0, 0, 0, 0, v0, vn, npv, cut_off, ped, None, 0)
+                for level, (t, p, x) in enumerate(levels):
+                    k_ref, extras = oracle.absorption_port(table, t, p, x, v0, vn, npv,
+                                                           cut_off=cut_off, remove_pedestal=ped,
+                                                           want_regions=True)
+                    if level < 3 and not ped:
+                        # the case is about the inner regions: make sure it reaches them
+                        assert extras["regions"][2:6].sum() > 1000, extras["regions"]
+                    k_plain = k_ref if not ped else oracle.absorption_port(
+                        table, t, p, x, v0, vn, npv, cut_off=cut_off)[0]
+                    assert_spectrum(k[level], k_ref, case,
+                                    f"inner cut={cut_off} npv={npv} P={points} far={farfield} "
+                                    f"level {level} ped={ped}", k_plain)
+    finally:
+        engine.set_option("points_per_lane", 0)
+        engine.set_option("farfield", 0)
+        engine.free(molecule)
+
+
+def test_levels_around_the_switch_of_the_inner_regions(engine, oracle):
+    """y >= 8.425 switches the inner regions off (voigt.c:35-43).  The engine skips its look for
+    inner points at levels where a host-side bound says no line can have y below that; pressures
+    on both sides of the switch for tables with narrow and with wide ranges of half-widths must
+    give what the reference gives."""
+    from pylbl_amd import synthetic
+    for seed, spread in ((5, 1.0), (6, 0.05), (7, 8.0)):
+        table = synthetic.line_table("CO2", 900., 960., num_lines=3000, seed=seed,
+                                     tips_range=(150, 400))
+        table.gamma_air = 0.07 + (table.gamma_air - 0.075)*spread
+        table.gamma_self = 0.1 + (table.gamma_self - 0.275)*spread
+        table.gamma_air = np.abs(table.gamma_air) + 1e-4
+        table.gamma_self = np.abs(table.gamma_self) + 1e-4
+        molecule = engine.load(table)
+        # alpha ~ 9e-4 cm-1 here: y = 0.83 gamma p/alpha crosses 8.425 near p = 0.13 atm
+        pressure = 101325.*np.asarray([0.02, 0.08, 0.11, 0.125, 0.135, 0.15, 0.2, 0.5, 1.0, 3.0])
+        t = np.full(pressure.size, 260.)
+        x = np.full(pressure.size, 4e-4)
+        v0, vn, npv = 915, 945, 1000
+        k = engine.compute(molecule, t, pressure, x, v0, vn, npv)
+        case = golden_io.Case("switch", 0, 0, 0, 0, v0, vn, npv, 25, False, None, 0)
+        seen = []
+        for level in range(pressure.size):
+            k_ref, extras = oracle.absorption_port(table, t[level], pressure[level], x[level], v0,
+                                                   vn, npv, want_regions=True)
+            seen.append(int(extras["regions"][2:6].sum()))
+            assert_spectrum(k[level], k_ref, case, f"switch seed {seed} level {level}")
+        assert seen[0] > 1000 and seen == sorted(seen, reverse=True), seen
+        if spread < 1.:
+            assert seen[-1] == 0, seen      # narrow range of half-widths: the switch is sharp
+        engine.free(molecule)
+
+
 def test_extreme_levels(engine, oracle):
     """Near-vacuum (y <= 1e-6: w4 regions switched off, voigt.c:48-53) and very high
     pressure (every line Lorentz-only, voigt.c:17-27), hot and cold."""
