@@ -54,6 +54,15 @@ extern "C" {
                                    every line core) enter through one power series per tile
                                    instead of point by point -- truncation <= ~1.5e-11 relative,
                                    3-4x faster at 0.001 cm-1 (same as option "farfield" = 1)  */
+#define LBL_DEFER_FINISH   32   /* with LBL_ASYNC | LBL_OUT_DEVICE and remove_pedestal: everything
+                                 * is queued except the last kernels, which apply the pedestal
+                                 * to k (and the copies of lbl_compute_streamed): those wait for
+                                 * lbl_finish_deferred (or lbl_synchronize).  A long call can
+                                 * then be queued FIRST and still be the LAST to add into a block
+                                 * other calls write meanwhile -- the reference's loop has no
+                                 * such order to keep, its calls are serial (spectroscopy.py:166).
+                                 * One deferred call at a time; ignored where it cannot apply
+                                 * (no pedestal, several level passes, host output). */
 
 typedef struct lbl_engine lbl_engine;
 
@@ -108,7 +117,14 @@ int lbl_compute_streamed(lbl_engine *engine, int32_t molecule, int32_t n_levels,
                          double *k, int64_t level_stride, void *host, int64_t host_pitch,
                          int64_t columns, int32_t pieces);
 
-/* Waits for everything enqueued on the engine (all of its streams). */
+/* Queues the part of a call that LBL_DEFER_FINISH kept back (no-op without one).  lbl_deferred:
+ * 1 while a call is kept back, 0 otherwise -- in particular right after a call whose
+ * LBL_DEFER_FINISH could not be honoured and which therefore finished at once. */
+int lbl_finish_deferred(lbl_engine *engine);
+int lbl_deferred(const lbl_engine *engine);
+
+/* Waits for everything enqueued on the engine (all of its streams); a deferred call is finished
+ * first. */
 int lbl_synchronize(lbl_engine *engine);
 
 /* Zeroes n_levels rows of n doubles (row stride level_stride, 0 = dense) of host memory, or of

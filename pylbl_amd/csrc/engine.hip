@@ -154,6 +154,27 @@ struct Lane
     hipEvent_t handed_over = nullptr;   // what a caller's stream waits for (lbl_order_stream_after_engine)
     hipEvent_t piece_done[8] = {};      // behind the last kernel of each piece of a streamed call
     hipEvent_t piece_summed[8] = {};    // behind a piece's accumulate launch (pedestal: applied elsewhere)
+    // The last part of a call with a pedestal -- the kernels that apply it to the caller's block,
+    // piece by piece, and the copies of a streamed call -- kept back until lbl_finish_deferred
+    // (LBL_DEFER_FINISH): everything before works in the lane's own buffers, so a long call can be
+    // queued FIRST and still be the LAST to add into a block other calls write meanwhile.
+    struct Finish
+    {
+        bool pending = false;
+        int pieces = 1, count = 0, n_cells = 0, flags = 0;
+        long long point_begin[9] = {};      // piece p covers points [point_begin[p], point_begin[p+1])
+        int n_per_v = 0;
+        const double * sums = nullptr;
+        long long sums_stride = 0;
+        double * target = nullptr;
+        long long target_stride = 0;
+        bool streamed = false, order_writers = false, add_into = false;
+        char * host = nullptr;
+        long long host_pitch = 0, columns = 0, base = 0;
+        double * k = nullptr;
+        long long out_bytes = 0;
+        hipStream_t finish_stream = nullptr;
+    } finish;
     // The last few writes of device output queued on this lane: where, and an event behind the
     // kernel that wrote.  A call on another lane that touches the same memory waits for it.
     struct Write { const char * begin = nullptr; const char * end = nullptr; hipEvent_t done = nullptr; };
@@ -445,6 +466,72 @@ struct lbl_engine
                 HIP_TRY(hipStreamWaitEvent(stream, lane.writes[lane.next_write].done, 0));
             }
         }
+    }
+
+    Lane * deferred = nullptr;      // the lane whose call waits for lbl_finish_deferred
+
+    // Queues what Lane::Finish describes: apply kernels (+ copies) of every piece, then ties the
+    // lane's main stream and the block's write record to the last of them.
+    void run_finish(Lane & lane)
+    {
+        Lane::Finish & f = lane.finish;
+        hipStream_t stream = lane.main;
+        if (f.order_writers)
+        {
+            order_after_writers(f.finish_stream, f.k, f.out_bytes, &lane);
+        }
+        for (int piece = 0; piece < f.pieces; ++piece)
+        {
+            const long long q0 = f.point_begin[piece], q1 = f.point_begin[piece + 1];
+            if (q1 <= q0) continue;
+            if (f.finish_stream != stream)
+            {
+                // (recorded behind this piece's accumulate launch)
+                HIP_TRY(hipStreamWaitEvent(f.finish_stream, lane.piece_summed[piece], 0));
+            }
+            dim3 grid((unsigned)((q1 - q0 + 255)/256), (unsigned)f.count);
+            hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, f.finish_stream, f.sums,
+                               f.sums_stride, f.target, f.target_stride,
+                               lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
+                               lane.levels.data, (int)q0, (int)q1, f.n_per_v, f.n_cells,
+                               (f.flags & LBL_SCALE_DENSITY) ? 1 : 0, f.add_into ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            if (f.streamed && q0 < f.columns)
+            {
+                // This piece's columns go home beside the kernels of the next.  (The runtime's
+                // device-to-host copy is a kernel of its own here, not a DMA engine; queued
+                // beside an accumulate grid it costs the grid nothing, and a hand-written copy
+                // kernel of 8..1024 workgroups did worse: profiles/r03_perf_deliver.txt.)
+                const long long c1 = std::min<long long>(q1, f.columns);
+                HIP_TRY(hipEventRecord(lane.piece_done[piece], f.finish_stream));
+                HIP_TRY(hipStreamWaitEvent(copy_stream, lane.piece_done[piece], 0));
+                HIP_TRY(hipMemcpy2DAsync(f.host + f.base*f.host_pitch + q0*8, (size_t)f.host_pitch,
+                                         f.target + q0, (size_t)f.target_stride*8,
+                                         (size_t)(c1 - q0)*8, (size_t)f.count,
+                                         hipMemcpyDeviceToHost, copy_stream));
+            }
+        }
+        if (f.finish_stream != stream)
+        {
+            // Later users of the lane's main stream (and of the block) come after the last apply.
+            HIP_TRY(hipEventRecord(lane.pedestal_done, f.finish_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
+        }
+        if (f.k != nullptr)
+        {
+            lane.note_write(f.k, f.out_bytes, stream);
+        }
+        f.pending = false;
+        if (deferred == &lane) deferred = nullptr;
+    }
+
+    void finish_deferred()
+    {
+        if (deferred != nullptr && deferred->finish.pending)
+        {
+            run_finish(*deferred);
+        }
+        deferred = nullptr;
     }
 
     // Orders `stream` (lane 0's) behind everything queued on the other lanes so far, without
@@ -829,7 +916,21 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         const bool alternate = (rq.flags & LBL_ASYNC) && want_k && rq.derived == nullptr &&
                                ((pedestal_pass && (!add_into_block || out_device)) ||
                                 (small && out_device && !add_into_block));
-        Lane & lane = engine->lanes[alternate ? (engine->next_lane++ % kLanes) : 0];
+        if (!alternate || (rq.flags & LBL_DEFER_FINISH))
+        {
+            // Lane 0's ordering covers every lane, and there is one deferral at a time.
+            engine->finish_deferred();
+        }
+        int lane_index = 0;
+        if (alternate)
+        {
+            lane_index = (int)(engine->next_lane++ % kLanes);
+            if (&engine->lanes[lane_index] == engine->deferred)
+            {
+                lane_index = (int)(engine->next_lane++ % kLanes);
+            }
+        }
+        Lane & lane = engine->lanes[lane_index];
         hipStream_t stream = lane.main;
         const long long out_bytes = ((long long)(rq.n_levels - 1)*stride + n_long)*8;
         if (!alternate)
@@ -896,6 +997,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         std::vector<LineWing> host_wing;
         std::vector<LineCore> host_core;
         std::vector<double> host_derived;
+        bool deferred_finish = false;
 
         for (long long base = 0; base < rq.n_levels; base += chunk)
         {
@@ -1127,35 +1229,15 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             // apply kernels follow it there, while the main stream goes on with the accumulate
             // launches of the later pieces), else on the main stream.
             hipStream_t finish_stream = with_pedestal ? ped_stream : stream;
-            auto finish_piece = [&](int piece) {
+            auto finish_piece = [&](int piece) {        // (without a pedestal: only the copy)
                 long long q0, q1;
                 point_range(piece, q0, q1);
                 if (q1 <= q0) return;
-                if (with_pedestal)
-                {
-                    if (finish_stream != stream)
-                    {
-                        // (recorded behind this piece's accumulate launch, below)
-                        HIP_TRY(hipStreamWaitEvent(finish_stream, lane.piece_summed[piece], 0));
-                    }
-                    dim3 grid((unsigned)((q1 - q0 + 255)/256), (unsigned)count);
-                    hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, finish_stream,
-                                       sums, sums_stride, target, target_stride,
-                                       lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
-                                       lane.levels.data, (int)q0, (int)q1, g.n_per_v, n_cells,
-                                       (rq.flags & LBL_SCALE_DENSITY) ? 1 : 0,
-                                       (out_device && add_into) ? 1 : 0);
-                    HIP_TRY(hipGetLastError());
-                }
                 if (streamed && q0 < rq.columns)
                 {
                     const long long c1 = std::min<long long>(q1, rq.columns);
-                    HIP_TRY(hipEventRecord(lane.piece_done[piece], finish_stream));
+                    HIP_TRY(hipEventRecord(lane.piece_done[piece], stream));
                     HIP_TRY(hipStreamWaitEvent(engine->copy_stream, lane.piece_done[piece], 0));
-                    // (The runtime's device-to-host copy is a kernel of its own here, not a DMA
-                    // engine; queued beside an accumulate grid it costs the grid nothing, and a
-                    // hand-written copy kernel of 8..1024 workgroups did worse:
-                    // profiles/r03_perf_deliver.txt.)
                     HIP_TRY(hipMemcpy2DAsync(rq.host + base*rq.host_pitch + q0*8,
                                              (size_t)rq.host_pitch, target + q0,
                                              (size_t)target_stride*8, (size_t)(c1 - q0)*8,
@@ -1204,20 +1286,48 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                     pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
                                     lane.core.data, g, count, n_cells, engine->scan_chain != 0);
                 });
-                if (alternate && out_device && add_into)
-                {
-                    engine->order_after_writers(finish_stream, rq.k, out_bytes, &lane);
-                }
+                Lane::Finish & f = lane.finish;
+                f.pieces = pieces;
+                f.count = count;
+                f.n_cells = n_cells;
+                f.n_per_v = g.n_per_v;
+                f.flags = rq.flags;
                 for (int piece = 0; piece < pieces; ++piece)
                 {
-                    finish_piece(piece);
+                    long long q0, q1;
+                    point_range(piece, q0, q1);
+                    f.point_begin[piece] = q0;
+                    f.point_begin[piece + 1] = std::max(q1, q0);
                 }
-                if (finish_stream != stream)
+                f.sums = sums;
+                f.sums_stride = sums_stride;
+                f.target = target;
+                f.target_stride = target_stride;
+                f.streamed = streamed;
+                f.order_writers = alternate && out_device && add_into;
+                f.add_into = out_device && add_into;
+                f.host = rq.host;
+                f.host_pitch = rq.host_pitch;
+                f.columns = rq.columns;
+                f.base = base;
+                // The block's write record: only once, behind the call's last pass.
+                const bool last_pass = base + count >= rq.n_levels;
+                f.k = (out_device && last_pass) ? rq.k : nullptr;
+                f.out_bytes = out_bytes;
+                f.finish_stream = finish_stream;
+                f.pending = true;
+                // Kept back for lbl_finish_deferred only if nothing of this call comes after it:
+                // one pass, spectra in device memory, the host not waiting.
+                deferred_finish = (rq.flags & LBL_DEFER_FINISH) && (rq.flags & LBL_ASYNC) &&
+                                  out_device && alternate && chunk >= rq.n_levels &&
+                                  rq.evals == nullptr;
+                if (deferred_finish)
                 {
-                    // Later users of the lane's main stream (and of the block) come after the
-                    // last apply kernel.
-                    HIP_TRY(hipEventRecord(lane.pedestal_done, finish_stream));
-                    HIP_TRY(hipStreamWaitEvent(stream, lane.pedestal_done, 0));
+                    engine->deferred = &lane;
+                }
+                else
+                {
+                    engine->run_finish(lane);
                 }
             }
 
@@ -1253,9 +1363,9 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
         }
 
-        if (out_device && want_k)
+        if (out_device && want_k && !with_pedestal)
         {
-            lane.note_write(rq.k, out_bytes, stream);
+            lane.note_write(rq.k, out_bytes, stream);   // (with a pedestal: run_finish does)
         }
         if (rq.evals != nullptr && !(engine->prep == LBL_PREP_HOST))
         {
@@ -1546,10 +1656,34 @@ int lbl_line_scalars(lbl_engine * engine, int32_t molecule, double temperature,
     return compute(engine, rq);
 }
 
+int lbl_deferred(const lbl_engine * engine)
+{
+    return (engine != nullptr && engine->deferred != nullptr && engine->deferred->finish.pending)
+           ? 1 : 0;
+}
+
+int lbl_finish_deferred(lbl_engine * engine)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        engine->finish_deferred();
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    return LBL_OK;
+}
+
 int lbl_synchronize(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
     (void)hipSetDevice(engine->device);
+    // A call still kept back (LBL_DEFER_FINISH) is finished first: nothing stays unapplied.
+    const int finished = lbl_finish_deferred(engine);
+    if (finished != LBL_OK) return finished;
     for (auto & lane : engine->lanes)
     {
         hipError_t status = hipStreamSynchronize(lane.main);

@@ -19,12 +19,13 @@ LIBRARY_PATH = Path(__file__).resolve().parent / "liblbl_amd.so"
 LBL_OK = 0
 RANGE_REFERENCE, RANGE_SKIP = 0, 1
 PREP_DEVICE, PREP_HOST = 0, 1
-OUT_DEVICE, ASYNC, SCALE_DENSITY, ACCUMULATE, FARFIELD = 1, 2, 4, 8, 16
+OUT_DEVICE, ASYNC, SCALE_DENSITY, ACCUMULATE, FARFIELD, DEFER_FINISH = 1, 2, 4, 8, 16, 32
 RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
 
 EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
-    "lbl_molecule_free", "lbl_compute", "lbl_compute_streamed", "lbl_synchronize", "lbl_set_option", "lbl_timing",
+    "lbl_molecule_free", "lbl_compute", "lbl_compute_streamed", "lbl_finish_deferred",
+    "lbl_deferred", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_order_stream_after_engine", "lbl_order_engine_after_stream",
     "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
@@ -106,6 +107,8 @@ def library():
     lib.lbl_compute_streamed.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                          c_void_p] + [c_int32]*7 + [c_void_p, c_int64, c_void_p,
                                                                     c_int64, c_int64, c_int32]
+    lib.lbl_finish_deferred.argtypes = [c_void_p]
+    lib.lbl_deferred.argtypes = [c_void_p]
     lib.lbl_synchronize.argtypes = [c_void_p]
     lib.lbl_set_option.argtypes = [c_void_p, c_char_p, c_int64]
     lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
@@ -346,20 +349,23 @@ class Engine(object):
     def compute(self, molecule, temperature, pressure, vmr, v0, vn, n_per_v, cut_off=25,
                 remove_pedestal=False, range_policy="reference", out=None, scale_density=False,
                 accumulate=False, asynchronous=False, want_evals=False, farfield=False,
-                deliver=None, pieces=4):
+                deliver=None, pieces=4, defer_finish=False):
         """Cross sections [m2] for every level: returns float64[levels, (vn-v0)*n_per_v]
         (or fills `out`: a host array or a DeviceSpectra).
 
         deliver: with a device `out`, a float64 [levels, columns] host view with contiguous rows
         (page-locked: Engine.host_array) that receives the first `columns` points of every level
-        while the call computes, in `pieces` runs of tiles (lbl_compute_streamed)."""
+        while the call computes, in `pieces` runs of tiles (lbl_compute_streamed).
+        defer_finish: keep the call's last kernels (the ones that touch `out`) back until
+        finish_deferred() / synchronize(): LBL_DEFER_FINISH."""
         t, p, x = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure)), \
             _f64(np.atleast_1d(vmr))
         if not (t.shape == p.shape == x.shape and t.ndim == 1):
             raise ValueError("temperature, pressure and vmr must be 1-d and equally long.")
         n = (int(vn) - int(v0))*int(n_per_v)
         flags = (SCALE_DENSITY if scale_density else 0) | (ACCUMULATE if accumulate else 0) | \
-                (ASYNC if asynchronous else 0) | (FARFIELD if farfield else 0)
+                (ASYNC if asynchronous else 0) | (FARFIELD if farfield else 0) | \
+                (DEFER_FINISH if defer_finish else 0)
         if hasattr(out, "pointer"):
             # Device memory: a DeviceSpectra or anything exposing .pointer and .shape.
             if tuple(out.shape) != (t.size, n):
@@ -417,6 +423,15 @@ class Engine(object):
             int(v0), int(vn), int(n_per_v), int(cut_off), 0, RANGE_POLICIES[range_policy],
             derived.ctypes.data))
         return derived[:int(num_lines)]
+
+    def finish_deferred(self):
+        """Queues what a call with defer_finish=True kept back."""
+        self._check(self.lib.lbl_finish_deferred(self.handle))
+
+    def deferred(self):
+        """True while a call is kept back (False right after a call whose defer_finish could
+        not be honoured: no pedestal pass, several level passes, host output)."""
+        return bool(self.lib.lbl_deferred(self.handle))
 
     def synchronize(self):
         self._check(self.lib.lbl_synchronize(self.handle))

@@ -90,7 +90,8 @@ class Gas(object):
     def absorption_coefficients(self, temperature, pressure, volume_mixing_ratio, grid,
                                 remove_pedestal=False, cut_off=25, range_policy="reference",
                                 out=None, scale_density=False, accumulate=False,
-                                asynchronous=False, farfield=False, deliver=None, pieces=4):
+                                asynchronous=False, farfield=False, deliver=None, pieces=4,
+                                defer_finish=False):
         """Batched form: one spectrum per level, float64[levels, (vn-v0)*n_per_v].
 
         farfield: sum the lines far from each tile of the grid through one power series per tile
@@ -123,7 +124,7 @@ class Gas(object):
                                    remove_pedestal=remove_pedestal, range_policy=range_policy,
                                    out=out, scale_density=scale_density, accumulate=accumulate,
                                    asynchronous=asynchronous, farfield=farfield,
-                                   deliver=deliver, pieces=pieces)
+                                   deliver=deliver, pieces=pieces, defer_finish=defer_finish)
 
     def __del__(self):
         try:

@@ -197,7 +197,6 @@ class Spectroscopy(object):
         self.farfield = bool(farfield)
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
         self.delivery_pieces = 4               # runs of tiles of the call that delivers its result
-        self.heaviest_first = False
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
         dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
@@ -309,20 +308,32 @@ class Spectroscopy(object):
                 engine = gas.engine if gas is not None else \
                     (continua_here[0].engine if continua_here else cross.engine)
             present.append((name, gas, continua_here, cross))
-        # The gas with the most transitions goes last: its lines call is the longest, and the
-        # one that can hand its block to the host while it computes; the blocks of the others
-        # travel beside the kernels of the gases behind them.  (Units are independent,
-        # spectroscopy.py:166,179; results are reported in the atmosphere's order.)
-        present.sort(key=lambda entry: entry[1].num_lines if entry[1] is not None else -1,
-                     reverse=self.heaviest_first)
+        # "total" (one block for everything): the gas with the most transitions is queued FIRST and
+        # finished LAST.  Its lines call is the longest (with the pedestal removed it ends in a serial
+        # chain), so everything it does
+        # in buffers of its own -- prologue, far-field series, accumulate, pedestal pre-pass --
+        # starts at once and runs beside the other gases' calls, while the kernels that touch its
+        # block, and the copies that hand that block to the host piece by piece, are kept back
+        # (LBL_DEFER_FINISH) until the others have been queued: it stays the last to add into a
+        # shared block, and its copies queue up behind the other gases' copies, not in front of
+        # them.  (Units are independent, spectroscopy.py:166,179; results are reported in the
+        # atmosphere's order.)
+        # Per-gas blocks ("gas", "all") are the other way round: the link to the host is the
+        # bottleneck there (one block per gas to copy), so the lightest gas goes first -- its block
+        # is complete early and travels beside the kernels of the others -- and the heaviest last,
+        # delivering its block piece by piece while it computes (profiles/r03_ab_api.txt).
+        present.sort(key=lambda entry: entry[1].num_lines if entry[1] is not None else -1)
+        heavy = present[-1] if present and present[-1][1] is not None else None
+        if heavy is not None and mode == "total":
+            present = [heavy] + present[:-1]
 
-        def lines_into(name, gas, block, deliver=None):
+        def lines_into(name, gas, block, deliver=None, defer=False):
             gas.absorption_coefficients(
                 temperature, pressure, mole_fractions[name], self.grid,
                 remove_pedestal=remove_pedestal, range_policy=range_policy,
                 scale_density=True, out=block.buffer, accumulate=block.take(),
                 asynchronous=True, farfield=self.farfield, deliver=deliver,
-                pieces=self.delivery_pieces)
+                pieces=self.delivery_pieces, defer_finish=defer)
 
         def slots_into(name, continua_here, cross, continuum_sum, cross_sum):
             for continuum in continua_here:
@@ -353,25 +364,32 @@ class Spectroscopy(object):
                         self.grid, temperature, pressure,
                         volume_mixing_ratio=mole_fractions[name])
         elif mode == "total" and present:
-            # Every gas adds into one block.  A gas's lines go first and its short continuum
-            # and cross-section kernels behind them (they run beside the next gas's lines, which
-            # work in buffers of their own until their last kernel) -- except for the gas that
-            # comes last: its lines call is the one that delivers, so it must be the last to add.
+            # Every gas adds into one block.  The heavy gas's slot kernels go first (the first of
+            # them writes the block -- or the engine clears it), then its lines call, kept back;
+            # the other gases' lines with their short continuum and cross-section kernels behind
+            # them; then the heavy gas's last kernels and the delivery of the finished block.
             total = _Sum(engine, levels, n)
             results["total"] = engine.host_array((levels, columns))
-            with_lines = [name for name, gas, _, _ in present if gas is not None]
-            for name, gas, continua_here, cross in present:
-                if with_lines and name == with_lines[-1]:
+            kept_back = False
+            for index, (name, gas, continua_here, cross) in enumerate(present):
+                if heavy is not None and index == 0:
+                    slots_into(name, continua_here, cross, total, total)
+                    if not total.written:
+                        engine.fill_zero(total.buffer, asynchronous=True)
+                        total.take()
+                    lines_into(name, gas, total, deliver=results["total"], defer=True)
+                    kept_back = engine.deferred()
                     continue
                 if gas is not None:
                     lines_into(name, gas, total)
                 slots_into(name, continua_here, cross, total, total)
-            if with_lines:
-                name, gas, continua_here, cross = [x for x in present if x[0] == with_lines[-1]][0]
-                slots_into(name, continua_here, cross, total, total)
-                lines_into(name, gas, total, deliver=results["total"])
+            if heavy is not None and kept_back:
+                engine.finish_deferred()
                 in_flight.append(total)
             else:
+                # (No gas with lines -- or a call the engine could not keep back, e.g. without a
+                # pedestal pass: it added at once and delivered a block that was not complete;
+                # this copy, queued behind everything, is the one that counts.)
                 in_flight.append(total.into(results["total"]))
         else:
             for index, (name, gas, continua_here, cross) in enumerate(present):

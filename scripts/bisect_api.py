@@ -7,8 +7,10 @@ os.environ.setdefault("PYLBL_MT_CKD", "/root/repo/tests/golden/mt_ckd_bands.npz"
 mode = sys.argv[1]
 if "torch" in mode:
     import torch
-    torch.cuda.set_device(0)
-    x = torch.zeros(10, device="cuda")
+    if "importonly" not in mode:
+        torch.cuda.set_device(0)
+        if "noalloc" not in mode:
+            x = torch.zeros(10, device="cuda")
 from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic
 from pylbl_amd.engine import default_engine, DeviceSpectra
 tables = [synthetic.line_table(f, 1., 5000.) for f in ("H2O", "CO2")]
@@ -29,7 +31,6 @@ if "pool" in mode:
     block = DeviceSpectra(e, 1, grid.size); target = e.host_array((1, grid.size)); block.to_host_into(target); block.free()
 spec = Spectroscopy(level, grid, MemoryDatabase(tables))
 spec.delivery_pieces = int(os.environ.get("PIECES", "4"))
-spec.heaviest_first = os.environ.get("HEAVIEST_FIRST", "0") == "1"
 for fmt in ("total", "gas"):
     for _ in range(4): spec.compute_absorption(fmt)
     start = time.perf_counter()

@@ -21,7 +21,6 @@ grid = np.arange(1., 5000., 0.001)
 for farfield in (True, False):
     spec = Spectroscopy(level, grid, MemoryDatabase(tables), farfield=farfield)
     for count in pieces:
-        spec.heaviest_first = count < 0
         spec.delivery_pieces = abs(count)
         row = []
         for fmt in ("total", "gas", "all"):

@@ -21,7 +21,6 @@ surface = synthetic.surface_level()
 level = synthetic.Atmos(p=surface.p, t=surface.t, vmr={f: surface.vmr[f] for f in formulae})
 grid = np.arange(1., 5000., 0.001)
 spec = Spectroscopy(level, grid, MemoryDatabase(tables))
-spec.heaviest_first = os.environ.get("HEAVIEST_FIRST", "0") == "1"
 spec.delivery_pieces = int(os.environ.get("PIECES", "4"))
 for _ in range(6):
     spec.compute_absorption(output_format="total")

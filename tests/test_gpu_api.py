@@ -580,6 +580,73 @@ def test_streamed_call_delivers_what_the_plain_call_computes(remove_pedestal, fa
     e.close()
 
 
+@pytest.mark.parametrize("farfield", [False, True])
+def test_deferred_finish_queued_first_adds_last(farfield):
+    """LBL_DEFER_FINISH: a long call is queued first -- prologue, accumulate, pedestal chain run at
+    once, in the lane's own buffers -- but the kernels that add into the caller's block (and the
+    piecewise delivery to the host) wait for lbl_finish_deferred, behind calls queued later.  The
+    block and the delivered array equal the plain sequence; where the engine cannot keep a call
+    back (no pedestal pass) it says so and finishes at once."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    heavy_table = synthetic.line_table("CO2", 1., 260., num_lines=60000, seed=15, tips_range=(150, 400))
+    light_table = synthetic.line_table("H2O", 1., 260., num_lines=8000, seed=16, tips_range=(150, 400))
+    heavy, light = e.load(heavy_table), e.load(light_table)
+    atmos = synthetic.standard_atmosphere(3)
+    v0, vn, npv = 1, 241, 1000
+    n = (vn - v0)*npv
+    args = (atmos.t, atmos.p)
+    # the plain sequence: light writes, heavy adds
+    expect = DeviceSpectra(e, 3, n)
+    e.compute(light, *args, atmos.vmr["H2O"], v0, vn, npv, remove_pedestal=True, out=expect,
+              scale_density=True, farfield=farfield)
+    e.compute(heavy, *args, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True, out=expect,
+              scale_density=True, accumulate=True, farfield=farfield)
+    want = expect.to_host()
+    for pieces in (1, 4):
+        block = DeviceSpectra(e, 3, n)
+        target = e.host_array((3, n - 500))
+        target[...] = -1.
+        e.fill_zero(block, asynchronous=True)
+        e.compute(heavy, *args, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True, out=block,
+                  scale_density=True, accumulate=True, asynchronous=True, farfield=farfield,
+                  deliver=target, pieces=pieces, defer_finish=True)
+        assert e.deferred()
+        e.compute(light, *args, atmos.vmr["H2O"], v0, vn, npv, remove_pedestal=True, out=block,
+                  scale_density=True, accumulate=True, asynchronous=True, farfield=farfield)
+        assert e.deferred()                 # a call on another lane leaves it kept back
+        e.finish_deferred()
+        assert not e.deferred()
+        e.synchronize()
+        got = block.to_host()
+        # same kernels, same values per call; only the order of the two additions differs
+        assert np.max(np.abs(got - want)) <= 4e-16*np.max(np.abs(want))
+        assert np.array_equal(target, got[:, :n - 500])
+        block.free()
+    # synchronize() finishes what is kept back
+    block = DeviceSpectra(e, 3, n)
+    e.fill_zero(block, asynchronous=True)
+    e.compute(heavy, *args, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True, out=block,
+              scale_density=True, accumulate=True, asynchronous=True, farfield=farfield,
+              defer_finish=True)
+    assert e.deferred()
+    e.synchronize()
+    assert not e.deferred() and block.to_host().any()
+    # without a pedestal pass there is nothing to keep back: the call adds at once
+    e.fill_zero(block, asynchronous=True)
+    e.compute(heavy, *args, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=False, out=block,
+              scale_density=True, accumulate=True, asynchronous=True, farfield=farfield,
+              defer_finish=True)
+    assert not e.deferred()
+    e.synchronize()
+    plain = e.compute(heavy, *args, atmos.vmr["CO2"], v0, vn, npv, scale_density=True,
+                      farfield=farfield)
+    assert np.array_equal(block.to_host(), plain)
+    block.free()
+    expect.free()
+    e.close()
+
+
 def test_compat_entry_device_and_cache(tmp_path):
     """The same-signature entry picks its GPU from LBL_DEVICE / the launcher's local rank,
     re-reads a database file that changed under the same path (the reference re-reads it on
