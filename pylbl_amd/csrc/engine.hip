@@ -192,6 +192,8 @@ struct Lane
     DeviceBuffer<double> raw;       // un-pedestalled sums when the output must be added to
     DeviceBuffer<double> partial;   // partial sums of split tiles
     DeviceBuffer<double> far_series; // [levels][tiles][kFarTerms]
+    DeviceBuffer<double> far_group;  // [levels][groups][kFarParts][kFarTerms]
+    DeviceBuffer<GroupCuts> group_cuts;  // [levels][groups]
     DeviceBuffer<double> derived;
     DeviceBuffer<unsigned long long> evals;
     PedestalWorkspace pedestal;
@@ -985,7 +987,13 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         lane.schedule.reserve((size_t)(chunk*n_tiles));
         if (want_k && !out_device) lane.staging.reserve((size_t)(chunk*n_long));
         if (with_pedestal && out_device && add_into) lane.raw.reserve((size_t)(chunk*n_long));
-        if (want_k && farfield) lane.far_series.reserve((size_t)(chunk*n_tiles*kFarTerms));
+        const int n_groups = (n_tiles + kFarGroup - 1)/kFarGroup;
+        if (want_k && farfield)
+        {
+            lane.far_series.reserve((size_t)(chunk*n_tiles*kFarTerms));
+            lane.far_group.reserve((size_t)(chunk*n_groups*kFarParts*kFarTerms));
+            lane.group_cuts.reserve((size_t)(chunk*n_groups));
+        }
         if (want_k) lane.partial.reserve((size_t)std::max(1ll, chunk*plan.partial_slots*64*points));
         if (rq.evals != nullptr)
         {
@@ -1204,9 +1212,17 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             if (farfield)
             {
                 engine->timed(kTimeAccumulate, stream, [&] {
+                    hipLaunchKernelGGL(farfield_group_kernel,
+                                       dim3((unsigned)n_groups, (unsigned)count, kFarParts),
+                                       dim3(256), 0, stream, lane.wing.data, lane.schedule.data,
+                                       m->d_column[0].data, lane.levels.data, n_lines, tiling,
+                                       n_groups, g.v0, g.n_per_v, g.n, g.dv, lane.group_cuts.data,
+                                       lane.far_group.data);
+                    HIP_TRY(hipGetLastError());
                     dim3 far_grid((unsigned)(((n_tiles + 7)/8)*8), (unsigned)count);
                     hipLaunchKernelGGL(farfield_kernel, far_grid, dim3(256), 0, stream,
-                                       lane.wing.data, lane.schedule.data, n_lines, tiling, g.v0,
+                                       lane.wing.data, lane.schedule.data, lane.group_cuts.data,
+                                       n_lines, tiling, lane.far_group.data, n_groups, g.v0,
                                        g.n_per_v, g.n, g.dv, lane.far_series.data);
                     HIP_TRY(hipGetLastError());
                 }, 0);

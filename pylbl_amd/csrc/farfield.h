@@ -11,9 +11,10 @@
 // a power series with convergence radius sqrt(D) >= |a|.  The schedule kernel only hands
 // over lines with |a| >= kFarRatio x the tile's half width, so |u|/|a| <= 1/4 and kFarTerms
 // = 21 terms leave a relative truncation below ~1.5e-11 (measured on the 5 M-point benchmark:
-// max 2.8e-12 against the direct kernel) -- five orders inside the 1e-6 parity bar.  The series of all far lines of a tile are ADDED coefficient by coefficient
-// (3 flops per line and term instead of ~5 flops per line and grid point), and the
-// accumulate kernel evaluates the summed polynomial once per point.
+// max 2.8e-12 against the direct kernel) -- five orders inside the 1e-6 parity bar.  The series
+// of all far lines of a tile are ADDED coefficient by coefficient (3 flops per line and term
+// instead of ~5 flops per line and grid point), and the accumulate kernel evaluates the summed
+// polynomial once per point.
 //
 // This is an algorithmic shortcut, not the reference's evaluation order: it is off by
 // default and `bench.py` reports it separately.
@@ -22,41 +23,86 @@
 #include <hip/hip_runtime.h>
 
 #include "accumulate.h"
+#include "line_prep.h"
+#include "wave_ops.h"
 
 namespace lbl {
 
-// One 256-thread workgroup per (tile, level); thread = line (strided), then a block sum.
-__global__ __launch_bounds__(256) void farfield_kernel(const LineWing * __restrict__ wing,
-                                                       const TileSchedule * __restrict__ schedule,
-                                                       long long n_lines, Tiling tiling,
-                                                       int v0, int n_per_v, int n, double dv,
-                                                       double * __restrict__ far_series)
-{
-    __shared__ double wave_sum[4][kFarTerms];
-    const int level = blockIdx.y;
-    // Neighbouring tiles read almost the same lines: one contiguous eighth of the spectrum
-    // per XCD keeps them in that XCD's L2 (speed only).
-    const int per_xcd = (tiling.n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiling.n_tiles)
-    {
-        return;
-    }
-    const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
-    const LineWing * __restrict__ w = wing + (long long)level*n_lines;
-    long long i0, i1;
-    tile_bounds(tiling, tile, n_per_v, n, i0, i1);
-    const double u0 = tile_centre(v0, dv, i0, i1);
+// Two levels (round 3).  Every tile used to walk the ~50 cm-1 worth of lines whose windows cover
+// it (~3800 of a 400 k-line table: 63 fp64 operations each, and 133 KB of records through L2),
+// yet most of those lines are far enough away to be expanded about the centre of a GROUP of kFarGroup adjacent tiles just as well: a line at least
+// kFarRatio group half-widths from the group's centre (and beyond every core) converges at the
+// same rate over the whole group as a tile's lines do over the tile.  So
+//   farfield_group_kernel   per group: the very far lines, read once for kFarGroup tiles, and
+//                           the cut points that say which lines those are;
+//   farfield_kernel         per tile: what is left -- the lines between the tile's own limit
+//                           and the group's, and the few whose windows cover this tile but not
+//                           the whole group -- plus the group's polynomial re-centred on the
+//                           tile (a Taylor shift by the distance d of the two centres,
+//                           s'_j = sum_{k>=j} C(k,j) s_k d^(k-j): an identity of polynomials,
+//                           so nothing is truncated twice);
+// and the accumulate kernel evaluates one polynomial per point as before.  Reads and arithmetic
+// drop ~2.9x for kFarGroup = 4.
+constexpr int kFarGroup = 4;
+// A group's lines may be shared out over kFarParts workgroups whose sums the tile kernel adds in a
+// fixed order.  Measured (5 M points, 400 k lines): 1 part 28 us, 2 parts 35 us, 4 parts 70 us per
+// launch -- the kernels are bound by instruction issue (the 63 fp64 operations per line and the
+// reduction per wavefront), not by the length of a thread's walk, so more workgroups only add
+// reductions.
+constexpr int kFarParts = 1;
 
+// First index in [lo, hi] whose wavenumber is > x (ABOVE) or >= x, found by a whole wavefront: 64
+// probes per step, so ~3400 candidates take two loads' latency where a binary search takes
+// twelve (the search is the serial head of its workgroup).
+template <bool ABOVE>
+__device__ inline int wave_search(const double * __restrict__ nu, int lo, int hi, double x)
+{
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 64)
+    {
+        const int stride = (hi - lo + 63) >> 6;
+        const int at = lo + lane*stride;
+        const bool below = at < hi && (ABOVE ? nu[at] <= x : nu[at] < x);
+        const int count = __builtin_popcountll(__ballot(below));
+        if (count == 0)
+        {
+            return lo;
+        }
+        const int base = lo + (count - 1)*stride;
+        hi = min(base + stride, hi);
+        lo = base + 1;
+    }
+    const int at = lo + lane;
+    const bool below = at < hi && (ABOVE ? nu[at] <= x : nu[at] < x);
+    return lo + __builtin_popcountll(__ballot(below));
+}
+
+struct GroupCuts
+{
+    int a1, g1, g2, a2;     // the group's very far lines: [a1, g1) below it, [g2, a2) above it
+};
+
+__device__ __forceinline__ void group_bounds(const Tiling & tiling, int group, int n_per_v, int n,
+                                             long long & i0, long long & i1)
+{
+    const int t0 = group*kFarGroup;
+    const int t1 = min(t0 + kFarGroup, tiling.n_tiles) - 1;
+    long long unused;
+    tile_bounds(tiling, t0, n_per_v, n, i0, unused);
+    tile_bounds(tiling, t1, n_per_v, n, unused, i1);
+}
+
+// Series of the lines [begin, end) of a list (index ranges laid end to end by `line_at`) about u0,
+// summed over the workgroup in a fixed order; thread k < kFarTerms returns term k (the others 0).
+template <typename LineAt>
+__device__ __forceinline__ double series_of_lines(const LineWing * __restrict__ w, int begin,
+                                                  int end, LineAt line_at, double u0,
+                                                  double (&wave_sum)[4][kFarTerms])
+{
     double c[kFarTerms];
 #pragma unroll
     for (int k = 0; k < kFarTerms; ++k) c[k] = 0.;
-    const int left = sc.f1 - sc.a1;
-    const int total = left + (sc.a2 - sc.f2);
-    for (int at = threadIdx.x; at < total; at += 256)
-    {
-        const int j = at < left ? sc.a1 + at : sc.f2 + (at - left);
-        const LineWing l = w[j];
+    auto add_line = [&](const LineWing & l) {
         const double a = l.centre - u0;
         const double r = rcp_newton(__builtin_fma(a, a, l.g2));
         const double s = (a + a)*r;
@@ -72,26 +118,187 @@ __global__ __launch_bounds__(256) void farfield_kernel(const LineWing * __restri
             q0 = q1;
             q1 = q2;
         }
-    }
-    // Sum over the 64 lanes (butterfly), then over the 4 wavefronts: fixed order.
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kFarTerms; ++k)
+    };
+    int at = begin + (int)threadIdx.x;
+    for (; at + 256 < end; at += 512)       // two loads in flight
     {
-        double value = c[k];
-        for (int offset = 32; offset > 0; offset >>= 1)
-        {
-            value += __shfl_xor(value, offset, 64);
-        }
-        if (lane == 0) wave_sum[wave][k] = value;
+        const LineWing l0 = w[line_at(at)];
+        const LineWing l1 = w[line_at(at + 256)];
+        add_line(l0);
+        add_line(l1);
     }
+    if (at < end)
+    {
+        add_line(w[line_at(at)]);
+    }
+    // Sum over the 64 lanes (wave_ops.h: 21 butterflies through the LDS crossbar were most of
+    // this kernel's time), then over the 4 wavefronts: fixed order.
+    const int wave = threadIdx.x >> 6;
+    int index;
+    bool valid;
+    wave_sums(c, index, valid);
+    if (valid) wave_sum[wave][index] = c[0];
     __syncthreads();
+    double term = 0.;
     if (threadIdx.x < kFarTerms)
     {
         const int k = threadIdx.x;
-        far_series[((long long)level*tiling.n_tiles + tile)*kFarTerms + k] =
-            (wave_sum[0][k] + wave_sum[1][k]) + (wave_sum[2][k] + wave_sum[3][k]);
+        term = (wave_sum[0][k] + wave_sum[1][k]) + (wave_sum[2][k] + wave_sum[3][k]);
+    }
+    return term;
+}
+
+// One 256-thread workgroup per (group, level, part).
+__global__ __launch_bounds__(256) void farfield_group_kernel(
+    const LineWing * __restrict__ wing, const TileSchedule * __restrict__ schedule,
+    const double * __restrict__ nu, const LevelScalars * __restrict__ levels, long long n_lines,
+    Tiling tiling, int n_groups, int v0, int n_per_v, int n, double dv,
+    GroupCuts * __restrict__ cuts, double * __restrict__ group_series)
+{
+    __shared__ double wave_sum[4][kFarTerms];
+    __shared__ GroupCuts shared_cuts;
+    const int level = blockIdx.y;
+    const int group = blockIdx.x;
+    if (group >= n_groups)
+    {
+        return;
+    }
+    long long i0, i1;
+    group_bounds(tiling, group, n_per_v, n, i0, i1);
+    const double u0 = tile_centre(v0, dv, i0, i1);
+    if (threadIdx.x < 128)
+    {
+        // The schedule's far limit (schedule_tile: cases 6 and 7) with the group's half width:
+        // wavefront 0 finds the cut below the group, wavefront 1 the one above it.
+        const bool below = threadIdx.x < 64;
+        const LevelScalars & lv = levels[level];
+        const double v_lo = (double)v0 + (double)i0*dv, v_hi = (double)v0 + (double)i1*dv;
+        const double half = 0.5*(v_hi - v_lo);
+        const double kk = lv.core_reach;
+        const bool bounded = kk < 0.5;
+        const double core = bounded ? kk*(v_hi + lv.shift_max)/(1. - kk)*(1. + 1.e-9) +
+                                      lv.shift_max + 1.e-9 : 0.;
+        const double radius = fmax(kFarRatio*half, core + half)*(1. + 1.e-9) + 1.e-6;
+        // Lines that cover every tile of the group: the tightest of the tiles' ranges.
+        const int t0 = group*kFarGroup, t1 = min(t0 + kFarGroup, tiling.n_tiles);
+        int a1 = 0, a2 = (int)n_lines, f1 = (int)n_lines, f2 = 0;
+        for (int t = t0; t < t1; ++t)
+        {
+            const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + t];
+            a1 = max(a1, sc.a1);
+            a2 = min(a2, sc.a2);
+            f1 = min(f1, sc.f1);
+            f2 = max(f2, sc.f2);
+        }
+        // Never beyond what every tile hands to its own series (f1, f2), never outside [a1, a2):
+        // the search is confined to that range.
+        if (below)
+        {
+            const int g1 = bounded && f1 > a1
+                ? wave_search<true>(nu, a1, f1, u0 - radius - lv.shift_max) : a1;
+            if (threadIdx.x == 0)
+            {
+                shared_cuts.a1 = a1;
+                shared_cuts.g1 = g1;
+            }
+        }
+        else
+        {
+            const int g2 = bounded && a2 > f2
+                ? wave_search<false>(nu, f2, a2, u0 + radius + lv.shift_max) : a2;
+            if (threadIdx.x == 64)
+            {
+                shared_cuts.a2 = a2;
+                shared_cuts.g2 = g2;
+            }
+        }
+    }
+    __syncthreads();
+    const GroupCuts gc = shared_cuts;
+    const int part = blockIdx.z;
+    if (threadIdx.x == 0 && part == 0)
+    {
+        cuts[(long long)level*n_groups + group] = gc;
+    }
+    const int left = max(gc.g1 - gc.a1, 0);
+    const int total = left + max(gc.a2 - gc.g2, 0);
+    const int share = (total + kFarParts - 1)/kFarParts;
+    const double term = series_of_lines(
+        wing + (long long)level*n_lines, min(part*share, total), min((part + 1)*share, total),
+        [&](int at) { return at < left ? gc.a1 + at : gc.g2 + (at - left); }, u0, wave_sum);
+    if (threadIdx.x < kFarTerms)
+    {
+        group_series[(((long long)level*n_groups + group)*kFarParts + part)*kFarTerms +
+                     threadIdx.x] = term;
+    }
+}
+
+// One 256-thread workgroup per (tile, level); thread = line (strided), then a block sum.
+__global__ __launch_bounds__(256) void farfield_kernel(const LineWing * __restrict__ wing,
+                                                       const TileSchedule * __restrict__ schedule,
+                                                       const GroupCuts * __restrict__ cuts,
+                                                       long long n_lines, Tiling tiling,
+                                                       const double * __restrict__ group_series,
+                                                       int n_groups, int v0, int n_per_v, int n,
+                                                       double dv,
+                                                       double * __restrict__ far_series)
+{
+    __shared__ double wave_sum[4][kFarTerms];
+    const int level = blockIdx.y;
+    // Neighbouring tiles read almost the same lines: one contiguous eighth of the spectrum
+    // per XCD keeps them in that XCD's L2 (speed only).
+    const int per_xcd = (tiling.n_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
+    if (tile >= tiling.n_tiles)
+    {
+        return;
+    }
+    const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
+    const GroupCuts gc = cuts[(long long)level*n_groups + tile/kFarGroup];
+    long long i0, i1;
+    tile_bounds(tiling, tile, n_per_v, n, i0, i1);
+    const double u0 = tile_centre(v0, dv, i0, i1);
+    // This tile's far lines [a1, f1) and [f2, a2) without the group's [gc.a1, gc.g1), [gc.g2, gc.a2):
+    // four pieces laid end to end.
+    const int l1 = min(max(gc.a1, sc.a1), sc.f1);       // [a1, l1): cover this tile, not the group
+    const int l2 = min(max(gc.g1, l1), sc.f1);          // [l2, f1): nearer than the group's limit
+    const int r2 = max(min(gc.a2, sc.a2), sc.f2);       // [r2, a2)
+    const int r1 = max(min(gc.g2, r2), sc.f2);          // [f2, r1)
+    const int n0 = l1 - sc.a1, n1 = sc.f1 - l2, n2 = r1 - sc.f2, n3 = sc.a2 - r2;
+    const double own = series_of_lines(
+        wing + (long long)level*n_lines, 0, n0 + n1 + n2 + n3,
+        [&](int at) {
+            if (at < n0) return sc.a1 + at;
+            at -= n0;
+            if (at < n1) return l2 + at;
+            at -= n1;
+            if (at < n2) return sc.f2 + at;
+            return r2 + (at - n2);
+        }, u0, wave_sum);
+    if (threadIdx.x < kFarTerms)
+    {
+        // The group's polynomial in w = u + d about this tile's centre.
+        const int j = threadIdx.x;
+        long long g0, g1;
+        group_bounds(tiling, tile/kFarGroup, n_per_v, n, g0, g1);
+        const double d = u0 - tile_centre(v0, dv, g0, g1);
+        const double * __restrict__ gs =
+            group_series + ((long long)level*n_groups + tile/kFarGroup)*kFarParts*kFarTerms;
+        double shifted = 0., weight = 1.;       // weight = C(j+m, j) d^m
+#pragma unroll
+        for (int m = 0; m < kFarTerms; ++m)
+        {
+            if (j + m < kFarTerms)
+            {
+                const double * __restrict__ at = gs + j + m;
+                double term = at[0];
+#pragma unroll
+                for (int part = 1; part < kFarParts; ++part) term += at[part*kFarTerms];
+                shifted = __builtin_fma(term, weight, shifted);
+                weight *= d*((double)(j + m + 1)*(1./(double)(m + 1)));
+            }
+        }
+        far_series[((long long)level*tiling.n_tiles + tile)*kFarTerms + j] = own + shifted;
     }
 }
 

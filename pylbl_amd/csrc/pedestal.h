@@ -38,6 +38,7 @@
 
 #include "line_prep.h"
 #include "tile_schedule.h"
+#include "wave_ops.h"
 #include "voigt_profile.h"
 
 namespace lbl {
@@ -429,37 +430,6 @@ __device__ __forceinline__ double shuffle_up(double value, int offset)
     return __shfl_up(value, offset, 64);
 }
 
-// Lane-to-lane moves by data-parallel primitives (DPP): the operand of a VALU instruction is
-// taken from another lane of the row of 16 (row_shr:n), from the last lane of the previous row
-// (row_bcast:15, rows 1 and 3) or from lane 31 (row_bcast:31, rows 2 and 3) -- a few cycles,
-// where a shuffle through the LDS crossbar (ds_bpermute) is a round trip of ~100.  The chain
-// below is one wavefront whose every step waits for the previous one: its scans are the serial
-// path of the whole pedestal pass.  Lanes without a source keep `fill`.
-template <int CONTROL, int ROWS>
-__device__ __forceinline__ double dpp_from(double fill, double value)
-{
-    const long long f = __double_as_longlong(fill), v = __double_as_longlong(value);
-    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)v, CONTROL, ROWS, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(v >> 32), CONTROL, ROWS, 0xf,
-                                               false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
-constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143;
-
-// Inclusive prefix sums over the 64 lanes (Kogge-Stone inside the rows, then the row totals).
-__device__ __forceinline__ double wave_prefix_sum(double x)
-{
-    x += dpp_from<kRowShr1, 0xf>(0., x);
-    x += dpp_from<kRowShr2, 0xf>(0., x);
-    x += dpp_from<kRowShr4, 0xf>(0., x);
-    x += dpp_from<kRowShr8, 0xf>(0., x);
-    x += dpp_from<kRowBcast15, 0xa>(0., x);
-    x += dpp_from<kRowBcast31, 0xc>(0., x);
-    return x;
-}
-
 // Inclusive scan over lanes 0..31 of the composition of L -> min(L + a, c): the element (a, c)
 // of a lane becomes (sum of the a's up to it, the smallest c_i + (a's after i)).  Lanes 32..63
 // must hold the identity (0, inf); they are left undefined.
@@ -524,7 +494,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
             {
                 staged[i] = link[staged_from + i];
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();   // one wavefront: LDS keeps its order
         }
         const int r = b + lane;
         const bool candidate = lane < kScanBlock && r < staged_to;
@@ -599,8 +569,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
         static_assert(kScanBlock == 32, "half_wave_min_plus_scan covers lanes 0..31");
         half_wave_min_plus_scan(a, c);
         const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
-        double before = shuffle_up(total, 1);
-        if (lane == 0) before = 0.;
+        const double before = dpp_from<kWaveShr1, 0xf>(0., total);     // lane 0 keeps 0
         // P_r = L_r - L_{r-1}; on the branch L_r = L_{r-1} + a it is a itself, exactly.
         const double pedestal = (before + a_own <= c_own) ? a_own : c_own - before;
         if (active)
@@ -608,7 +577,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
             history[r & 127] = pedestal;
             if (mine.bin >= 0 && mine.bin < n_bins) atomicAdd(&bins[mine.bin], pedestal);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         b += size;
     }
     __syncthreads();
