@@ -121,7 +121,8 @@ struct AccumulateArgs
     int scale_density;
     int accumulate;
     int inner_everywhere;           // 0: only the core-range lines can have inner points in a tile
-    int ablate;                     // diagnostics only: 1 skips the general ranges, 2 the fast ranges
+    int ablate;                     // diagnostics only: 1 skips the general ranges, 2 the fast ranges,
+                                    // ..., 64 sends the clipped windows line by line (accumulate_tile)
 };
 
 // Far-wing loop over two index ranges [a0,a1) and [b0,b1) whose lines all cover the whole
@@ -487,6 +488,68 @@ __device__ __forceinline__ void general_ranges(const LineWing * __restrict__ win
     }
 }
 
+// The lines whose windows END inside the tile (ranges [lo,a1) and [a2,hi)), when the cut-off is
+// wide enough that the tile lies in the Lorentz wing of every one of them (the host's test,
+// AccumulateArgs::inner_everywhere == 0).  Windows begin and end on integer wavenumbers
+// (spectra.c:48-62), so neighbours in the sorted table mostly share theirs: eight lines with the
+// same [first, last] are summed like a far-wing group -- one reciprocal, rows outside the window
+// skipped, the row the window ends in masked -- instead of line by line, row by row.  On grids
+// whose tiles are aligned to the 1 cm-1 cells this is the closing point of ~80 windows on the
+// first tile of every cell; on coarse grids (100 points per cm-1) a tenth of all (line, tile)
+// pairs.  Groups that straddle a change of window, and what is left over, go line by line.
+template <int P>
+__device__ __forceinline__ void clipped_ranges(const LineWing * __restrict__ wing,
+                                               const LineCore * __restrict__ core,
+                                               int begin0, int count0, int begin1, int count1,
+                                               int i0, int i1, int lane,
+                                               const double (&v)[P], double (&acc)[P])
+{
+    const int total = count0 + count1;
+    int k = 0;
+    while (k < total)
+    {
+        const int j = k < count0 ? begin0 + k : begin1 + (k - count0);
+        const bool room = k < count0 ? k + 8 <= count0 : k + 8 <= total;
+        if (room)
+        {
+            // Lanes 0-7 (and their copies) look at the eight windows; the records are asked for
+            // at the same time (one round trip, not two: they are rarely not wanted).
+            const LineWing * __restrict__ mine = wing + j + (lane & 7);
+            const int my_first = mine->first, my_last = mine->last;
+            WingTerm l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const LineWing w = wing[j + i];
+                l[i] = WingTerm{w.centre, w.g2, w.bl};
+            }
+            const int first = __builtin_amdgcn_readfirstlane(my_first);
+            const int last = __builtin_amdgcn_readfirstlane(my_last);
+            if (__ballot(my_first != first || my_last != last) == 0)
+            {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                {
+                    const int r0 = i0 + p*64;
+                    if (last < r0 || first > r0 + 63)
+                    {
+                        continue;
+                    }
+                    const int i = r0 + lane;
+                    const double sum = lorentz_eight(v[p], l, acc[p]);
+                    acc[p] = (i >= first && i <= last) ? sum : acc[p];
+                }
+                k += 8;
+                continue;
+            }
+        }
+        const LineWing w = wing[j];
+        const LineCore c = core[j];
+        general_line<P>(w, c, i0, i1, lane, v, acc);
+        k += 1;
+    }
+}
+
 // The second pass over the lines of the general list, kInnerQueue at a time with lane = line
 // (their records arrive by one coalesced gather): the inner points the rows left out.  Kept
 // apart from the walk above on purpose -- the two need different registers, and as one loop each
@@ -570,11 +633,14 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     const int piece = item.part*4 + wave, pieces = item.parts*4;
     GeneralList g;
     int fa0, fa1, fb0, fb1, e;
-    share_of(sc.lo, sc.a1, piece, pieces, 1, g.begin[0], e);
+    // (The clipped windows are handed out eight lines at a time where clipped_ranges() sums them
+    // in groups of eight.)
+    const bool clipped_in_groups = !a.inner_everywhere && !(a.ablate & 64);
+    share_of(sc.lo, sc.a1, piece, pieces, clipped_in_groups ? 8 : 1, g.begin[0], e);
     g.count[0] = e - g.begin[0];
     share_of(sc.c1, sc.c2, piece, pieces, 1, g.begin[1], e);
     g.count[1] = e - g.begin[1];
-    share_of(sc.a2, sc.hi, piece, pieces, 1, g.begin[2], e);
+    share_of(sc.a2, sc.hi, piece, pieces, clipped_in_groups ? 8 : 1, g.begin[2], e);
     g.count[2] = e - g.begin[2];
     // [a1,f1) and [f2,a2) are summed by the far-field series (empty when that is off).
     share_of(sc.f1, sc.c1, piece, pieces, 4, fa0, fa1);
@@ -594,7 +660,14 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     bool slab_in_use = false;
     if (!(a.ablate & 1))
     {
-        general_ranges<P>(wing, core, g, i0, i1, lane, v, acc);
+        GeneralList walk = g;
+        if (clipped_in_groups)
+        {
+            clipped_ranges<P>(wing, core, g.begin[0], g.count[0], g.begin[2], g.count[2], i0, i1,
+                              lane, v, acc);
+            walk.count[0] = walk.count[2] = 0;
+        }
+        general_ranges<P>(wing, core, walk, i0, i1, lane, v, acc);
         // (32: diagnostics, leaves the inner points out.)  Levels at which no line of the call
         // can have an inner point -- the host's bound on y, engine.hip -- skip the look.
         if (!(a.ablate & 32) && a.levels[level].inner_possible != 0.)
@@ -691,11 +764,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
 
 // The eight-points-per-lane form (far-field series on: few lines per tile are evaluated point by
 // point, so the tile is made wide) with an occupancy hint.  Left alone the scheduler spends 108
-// VGPRs on it (4 wavefronts per SIMD); told that occupancy matters it makes do with 78, and the
-// far-field step gains 10-11 % (profiles/r03_ab_occupancy.txt).  The same hint on P <= 4 buys
-// nothing (71 instead of 75 VGPRs, +-0 to -1 %), so those are left to the compiler.
+// VGPRs on it (4 wavefronts per SIMD); asked for 4 per SIMD or more it made do with 78 and the
+// far-field step gained 10-11 % (profiles/r03_ab_occupancy.txt); with clipped_ranges() in the
+// kernel that hint gives 82 (5 wavefronts), asked for 6 it gives 80 and another 4 %
+// (profiles/r03_ab_clipped.txt).  The same hints on P <= 4 buy nothing (71 instead of 75 VGPRs,
+// +-0 to -1 %), so those are left to the compiler.
 template <>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6)))
 void accumulate_kernel<8>(const AccumulateArgs a)
 {
     accumulate_tile<8>(a);
