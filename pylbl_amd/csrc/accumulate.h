@@ -179,15 +179,45 @@ __device__ __forceinline__ void fast_ranges(const LineWing * __restrict__ wing,
 // evaluated inline.  Lanes closer to the centre than xlim1 add nothing here: the inner points of
 // all the lines walked here are summed afterwards, in a pass of their own (inner_ranges), into
 // the wavefront's LDS sums.
+// Which of a tile's rows (row p = grid indices [i0 + 64 p, i0 + 64 p + 63], p < rows <= 8) meet
+// the index range [a, b], and which lie wholly inside it: one bit per row.  The row-by-row
+// decisions below are wave-uniform and were, written as comparisons per row, ~19 scalar
+// instructions per row and line -- the scalar unit, one per CU, was the busiest unit of the kernel
+// wherever the general path carries the work (the far-field option: 183 M scalar against 139 M
+// vector instructions per launch).  As masks they cost ~10 scalar instructions per range and line
+// and a bit test per row.
+__device__ __forceinline__ unsigned row_bits(int lo, int hi, int rows)
+{
+    lo = max(lo, 0);
+    hi = min(hi, rows - 1);
+    return lo > hi ? 0u : ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
+__device__ __forceinline__ unsigned rows_meeting(int a, int b, int i0, int rows)
+{
+    return b < a ? 0u : row_bits((a - i0) >> 6, (b - i0) >> 6, rows);
+}
+
+__device__ __forceinline__ unsigned rows_inside(int a, int b, int i0, int rows)
+{
+    return b < a ? 0u : row_bits((a - i0 + 63) >> 6, (b - 63 - i0) >> 6, rows);
+}
+
 template <int P>
 __device__ __forceinline__ void general_line(const LineWing & l, const LineCore & c,
                                              int i0, int i1, int lane,
                                              const double (&v)[P], double (&acc)[P])
 {
-    if (l.last < i0 || l.first > i1)
+    const unsigned in_window = rows_meeting(l.first, l.last, i0, P);
+    if (in_window == 0)
     {
         return;     // also skips empty windows
     }
+    // Rows wholly inside the window and in w4 region 1 on every lane (line_prep.h), and rows
+    // that may hold a point of the core.
+    const unsigned all_region_one = rows_inside(c.mid_first, c.mid_last, i0, P) &
+                                    ~rows_meeting(c.hole_first, c.hole_last, i0, P);
+    const unsigned near_core = rows_meeting(c.core_first, c.core_last, i0, P);
     const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
     const double yq = c.y*c.y;
     const double a0 = yq + 0.5;                      // voigt.c:91-93
@@ -197,17 +227,24 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
-        const int r0 = i0 + p*64;
-        const int r1 = r0 + 63;
-        if (l.last < r0 || l.first > r1)
+        if (!(in_window & (1u << p)))
         {
+            continue;
+        }
+        const int r0 = i0 + p*64;
+        const double d = v[p] - l.centre;
+        if (all_region_one & (1u << p))
+        {
+            // voigt.c:95-96 with no selection left to make.
+            const double xi = d*c.repwid;
+            const double xq = xi*xi;
+            acc[p] += r1_scale*(a0 + xq)*rcp_newton(__builtin_fma(xq, d2 + xq, d0));
             continue;
         }
         const int i = r0 + lane;
         const bool inside = (i >= l.first) && (i <= l.last);
-        const double d = v[p] - l.centre;
         double value;
-        if (c.core_last < r0 || c.core_first > r1)
+        if (!(near_core & (1u << p)))
         {
             // voigt.c:82 / :24 in wavenumber units: the whole row is in the far wing.
             value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
@@ -237,8 +274,7 @@ __device__ __forceinline__ void general_line(const LineWing & l, const LineCore 
     }
 }
 
-// Up to five index ranges of lines in general position, walked as one list; records are
-// fetched two lines at a time so that the scalar-load latency is paid once per pair.
+// Up to five index ranges of lines in general position, walked as one list.
 struct GeneralList
 {
     int begin[5];
@@ -463,28 +499,108 @@ __device__ __forceinline__ bool inner_batch(const LineWing * __restrict__ wing,
     return true;
 }
 
+// A line of the core range [c1, c2): its window covers the whole tile (the range lies inside
+// [a1, a2)), so what is left to decide per row is `rows`, prepared by core_lines():
+//   bit p       row p lies wholly in w4 region 1 (and inside the window): no selection at all;
+//   bit 8 + p   row p may hold a point of the core: the reference's chain lane by lane;
+//   neither     the whole row is in the far wing.
+template <int P>
+__device__ __forceinline__ void core_line(const LineWing & l, const LineCore & c, unsigned rows,
+                                          const double (&v)[P], double (&acc)[P])
+{
+    const double rsqrpi = 0.56418958354775628695;   // 1/sqrt(pi)
+    const double yq = c.y*c.y;
+    const double a0 = yq + 0.5;                      // voigt.c:91-93
+    const double d0 = a0*a0;
+    const double d2 = yq + yq - 1.;
+    const double r1_scale = c.amp*rsqrpi*c.y;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+    {
+        const double d = v[p] - l.centre;
+        if (rows & (1u << p))
+        {
+            // voigt.c:95-96 with no selection left to make.
+            const double xi = d*c.repwid;
+            const double xq = xi*xi;
+            acc[p] += r1_scale*(a0 + xq)*rcp_newton(__builtin_fma(xq, d2 + xq, d0));
+        }
+        else if (!(rows & (256u << p)))
+        {
+            // voigt.c:82 / :24 in wavenumber units: the whole row is in the far wing.
+            acc[p] = __builtin_fma(l.bl, rcp_newton(__builtin_fma(d, d, l.g2)), acc[p]);
+        }
+        else
+        {
+            const double xi = d*c.repwid;               // voigt.c:76
+            const double abx = fabs(xi);
+            const double xq = abx*abx;
+            const bool far = abx >= c.xlim0;
+            const bool mid = !far && abx >= c.xlim1;
+            double value = 0.;
+            if (__any(far))
+            {
+                const double wing = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                value = far ? wing : value;
+            }
+            if (__any(mid))
+            {
+                const double w4 = r1_scale*(a0 + xq)*
+                                  rcp_newton(__builtin_fma(xq, d2 + xq, d0));
+                value = mid ? w4 : value;
+            }
+            acc[p] += value;
+        }
+    }
+}
+
+// The core range, two lines at a time.  The row masks of 64 lines are formed at once, lane =
+// line, by vector integer arithmetic (half an instruction per line where the scalar unit spent
+// ~35), and handed to the walk through v_readlane.
+template <int P>
+__device__ __forceinline__ void core_lines(const LineWing * __restrict__ wing,
+                                           const LineCore * __restrict__ core,
+                                           int begin, int count, int i0, int lane,
+                                           const double (&v)[P], double (&acc)[P])
+{
+    for (int base = 0; base < count; base += 64)
+    {
+        const int n = min(64, count - base);        // even: the caller keeps an odd line back
+        const LineCore * __restrict__ mine = core + begin + base + min(lane, n - 1);
+        const unsigned all_region_one = rows_inside(mine->mid_first, mine->mid_last, i0, P) &
+                                        ~rows_meeting(mine->hole_first, mine->hole_last, i0, P);
+        const unsigned near_core = rows_meeting(mine->core_first, mine->core_last, i0, P);
+        const unsigned packed = all_region_one | (near_core << 8);
+        for (int k = 0; k < n; k += 2)
+        {
+            const int j = begin + base + k;
+            const LineWing la = wing[j], lb = wing[j + 1];
+            const LineCore ca = core[j], cb = core[j + 1];
+            core_line<P>(la, ca, (unsigned)__builtin_amdgcn_readlane((int)packed, k), v, acc);
+            core_line<P>(lb, cb, (unsigned)__builtin_amdgcn_readlane((int)packed, k + 1), v, acc);
+        }
+    }
+}
+
 template <int P>
 __device__ __forceinline__ void general_ranges(const LineWing * __restrict__ wing,
                                                const LineCore * __restrict__ core,
                                                const GeneralList & g, int i0, int i1, int lane,
                                                const double (&v)[P], double (&acc)[P])
 {
-    const int total = g.count[0] + g.count[1] + g.count[2] + g.count[3] + g.count[4];
-    int k = 0;
-    for (; k + 2 <= total; k += 2)
+    // The core range (the bulk) ...
+    core_lines<P>(wing, core, g.begin[1], g.count[1] & ~1, i0, lane, v, acc);
+    // ... and its odd line with the few lines of the other ranges, one at a time.
+    GeneralList rest = g;
+    rest.begin[1] = g.begin[1] + (g.count[1] & ~1);
+    rest.count[1] = g.count[1] & 1;
+    const int total = rest.count[0] + rest.count[1] + rest.count[2] + rest.count[3] + rest.count[4];
+    for (int k = 0; k < total; ++k)
     {
-        const int ja = general_index(g, k), jb = general_index(g, k + 1);
-        const LineWing la = wing[ja], lb = wing[jb];
-        const LineCore ca = core[ja], cb = core[jb];
-        general_line<P>(la, ca, i0, i1, lane, v, acc);
-        general_line<P>(lb, cb, i0, i1, lane, v, acc);
-    }
-    if (k < total)
-    {
-        const int ja = general_index(g, k);
-        const LineWing la = wing[ja];
-        const LineCore ca = core[ja];
-        general_line<P>(la, ca, i0, i1, lane, v, acc);
+        const int j = general_index(rest, k);
+        const LineWing l = wing[j];
+        const LineCore c = core[j];
+        general_line<P>(l, c, i0, i1, lane, v, acc);
     }
 }
 
@@ -582,14 +698,22 @@ __device__ __forceinline__ bool inner_ranges(const LineWing * __restrict__ wing,
     return used;
 }
 
-// Contiguous share `part` of `parts` of the index range [j0, j1), in units of `unit` lines
-// (the last share also takes the remainder).
-__device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, int unit,
-                                         int & begin, int & end)
+// Contiguous share `part` of `parts` of the index range [j0, j1), in units of 1 << unit_shift lines
+// (the last share also takes the remainder).  The cut after share x is f(x) = trunc(units * (x *
+// (1/parts))) in single precision: any non-decreasing f does -- every wavefront forms its two cuts
+// from the same expression, so the shares tile the range whatever the rounding -- and this one
+// costs a handful of instructions where the exact 64-bit quotient cost the scalar unit some 150,
+// ten times per wavefront (a third of all scalar instructions of the far-field kernel).
+// `inverse` = 1.f/parts.
+__device__ __forceinline__ void share_of(int j0, int j1, int part, int parts, float inverse,
+                                         int unit_shift, int & begin, int & end)
 {
-    const int units = (j1 - j0)/unit;
-    begin = j0 + (int)(((long long)units*part)/parts)*unit;
-    end = (part + 1 == parts) ? j1 : j0 + (int)(((long long)units*(part + 1))/parts)*unit;
+    const int units = (j1 - j0) >> unit_shift;      // units of 1, 4 or 8 lines
+    const float scale = (float)units;
+    const int cut0 = min((int)(scale*((float)part*inverse)), units);
+    const int cut1 = min((int)(scale*((float)(part + 1)*inverse)), units);
+    begin = j0 + (cut0 << unit_shift);
+    end = (part + 1 == parts) ? j1 : j0 + (cut1 << unit_shift);
 }
 
 // One 256-thread workgroup per work item.  Its four wavefronts own the SAME 64*P grid points
@@ -636,15 +760,16 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     // (The clipped windows are handed out eight lines at a time where clipped_ranges() sums them
     // in groups of eight.)
     const bool clipped_in_groups = !a.inner_everywhere && !(a.ablate & 64);
-    share_of(sc.lo, sc.a1, piece, pieces, clipped_in_groups ? 8 : 1, g.begin[0], e);
+    const float inverse = 1.f/(float)pieces;
+    share_of(sc.lo, sc.a1, piece, pieces, inverse, clipped_in_groups ? 3 : 0, g.begin[0], e);
     g.count[0] = e - g.begin[0];
-    share_of(sc.c1, sc.c2, piece, pieces, 1, g.begin[1], e);
+    share_of(sc.c1, sc.c2, piece, pieces, inverse, 0, g.begin[1], e);
     g.count[1] = e - g.begin[1];
-    share_of(sc.a2, sc.hi, piece, pieces, clipped_in_groups ? 8 : 1, g.begin[2], e);
+    share_of(sc.a2, sc.hi, piece, pieces, inverse, clipped_in_groups ? 3 : 0, g.begin[2], e);
     g.count[2] = e - g.begin[2];
     // [a1,f1) and [f2,a2) are summed by the far-field series (empty when that is off).
-    share_of(sc.f1, sc.c1, piece, pieces, 4, fa0, fa1);
-    share_of(sc.c2, sc.f2, piece, pieces, 4, fb0, fb1);
+    share_of(sc.f1, sc.c1, piece, pieces, inverse, 2, fa0, fa1);
+    share_of(sc.c2, sc.f2, piece, pieces, inverse, 2, fb0, fb1);
     // Left-over lines of the far-wing ranges (fewer than four each) take the general path.
     g.begin[3] = fa0 + ((fa1 - fa0) & ~3);
     g.count[3] = (fa1 - fa0) & 3;

@@ -64,7 +64,15 @@ struct alignas(16) LineCore
     double xlim0;           // far-wing limit                    voigt.c:34
     double xlim1;           // w4 region-1 limit                 voigt.c:35-43, :48-53
     int core_first, core_last;  // grid indices that may fall inside |x| < xlim0 (conservative)
+    // Grid indices that CERTAINLY lie inside the window and inside |x| < xlim0 (one index and
+    // 1e-9 of the reach inside the limit), and the indices that may lie inside |x| < xlim1 (the
+    // range of inner_index_range(); empty when the line has no inner regions).  A 64-point row
+    // inside the first range and clear of the second is w4 region 1 on every lane
+    // (voigt.c:95-96): accumulate.h evaluates it without the per-lane region chain.
+    int mid_first, mid_last;
+    int hole_first, hole_last;
 };
+static_assert(sizeof(LineCore) == 64, "LineCore is read by scalar loads: 64 bytes");
 
 // An empty index range that intersects no row, tile or grid (including index 0).
 constexpr int kEmptyFirst = 0x3fffffff;
@@ -75,6 +83,24 @@ __host__ __device__ inline void mark_empty(LineWing & w, LineCore & c)
     w.centre = 0.; w.g2 = 1.; w.bl = 0.; w.first = kEmptyFirst; w.last = kEmptyLast;
     c.repwid = 1.; c.y = 100.; c.amp = 0.; c.xlim0 = 0.; c.xlim1 = 0.;
     c.core_first = kEmptyFirst; c.core_last = kEmptyLast;
+    c.mid_first = kEmptyFirst; c.mid_last = kEmptyLast;
+    c.hole_first = kEmptyFirst; c.hole_last = kEmptyLast;
+}
+
+// Grid indices that may fall inside |x| < xlim1, the inner regions of a line (w4 regions 2-3,
+// CPF12; voigt.c:98-186): conservative, with the margins of core_first / core_last above.
+__host__ __device__ inline void inner_index_range(double centre, double repwid, double xlim1,
+                                                  int v0, int n_per_v, int & first, int & last)
+{
+    const double near = (xlim1/repwid)*(1. + 1.e-9);
+    double lo = floor((centre - near - (double)v0)*n_per_v) - 1.;
+    double hi = floor((centre + near - (double)v0)*n_per_v) + 2.;
+    if (lo < -1.e9) lo = -1.e9;
+    if (hi > 1.e9) hi = 1.e9;
+    if (hi < -1.e9) hi = -1.e9;
+    if (lo > 1.e9) lo = 1.e9;
+    first = (int)lo;
+    last = (int)hi;
 }
 
 // status: 1 evaluated, 0 window right of the grid / empty, -1 not accepted by the range rule.
@@ -163,24 +189,22 @@ __host__ __device__ inline int prepare_line(const LevelScalars & lv, const GridS
         if (lo > 1.e9) lo = 1.e9;
         c.core_first = (int)lo;
         c.core_last = (int)hi;
+        const double sure = (xlim0/repwid)*(1. - 1.e-9);
+        double mid_lo = ceil((centre - sure - (double)g.v0)*g.n_per_v) + 1.;
+        double mid_hi = floor((centre + sure - (double)g.v0)*g.n_per_v) - 1.;
+        if (mid_lo < (double)first) mid_lo = (double)first;
+        if (mid_hi > (double)last) mid_hi = (double)last;
+        if (mid_hi >= mid_lo)
+        {
+            c.mid_first = (int)mid_lo;
+            c.mid_last = (int)mid_hi;
+        }
+        if (xlim1 > 0.)
+        {
+            inner_index_range(centre, repwid, xlim1, g.v0, g.n_per_v, c.hole_first, c.hole_last);
+        }
     }
     return status;
-}
-
-// Grid indices that may fall inside |x| < xlim1, the inner regions of a line (w4 regions 2-3,
-// CPF12; voigt.c:98-186): conservative, with the margins of core_first / core_last above.
-__host__ __device__ inline void inner_index_range(double centre, double repwid, double xlim1,
-                                                  int v0, int n_per_v, int & first, int & last)
-{
-    const double near = (xlim1/repwid)*(1. + 1.e-9);
-    double lo = floor((centre - near - (double)v0)*n_per_v) - 1.;
-    double hi = floor((centre + near - (double)v0)*n_per_v) + 2.;
-    if (lo < -1.e9) lo = -1.e9;
-    if (hi > 1.e9) hi = 1.e9;
-    if (hi < -1.e9) hi = -1.e9;
-    if (lo > 1.e9) lo = 1.e9;
-    first = (int)lo;
-    last = (int)hi;
 }
 
 }  // namespace lbl
