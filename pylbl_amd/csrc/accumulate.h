@@ -901,6 +901,13 @@ void accumulate_kernel<8>(const AccumulateArgs a)
     accumulate_tile<8>(a);
 }
 
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6)))
+void accumulate_kernel<4>(const AccumulateArgs a)
+{
+    accumulate_tile<4>(a);
+}
+
 // Adds up the partial sums of the split tiles, part 0 first (fixed order), and writes k.
 // One 64-thread group per (64-point row of a split tile, level).
 struct SplitTile
