@@ -430,10 +430,9 @@ __device__ __forceinline__ double shuffle_up(double value, int offset)
     return __shfl_up(value, offset, 64);
 }
 
-// Inclusive scan over lanes 0..31 of the composition of L -> min(L + a, c): the element (a, c)
-// of a lane becomes (sum of the a's up to it, the smallest c_i + (a's after i)).  Lanes 32..63
-// must hold the identity (0, inf); they are left undefined.
-__device__ __forceinline__ void half_wave_min_plus_scan(double & a, double & c)
+// Inclusive scan over the 64 lanes of the composition of L -> min(L + a, c): the element (a, c)
+// of a lane becomes (sum of the a's up to it, the smallest c_i + (a's after i)).
+__device__ __forceinline__ void wave_min_plus_scan(double & a, double & c)
 {
     const double inf = __builtin_inf();
 #define LBL_MIN_PLUS_STEP(CONTROL, ROWS)                                   \
@@ -448,10 +447,16 @@ __device__ __forceinline__ void half_wave_min_plus_scan(double & a, double & c)
     LBL_MIN_PLUS_STEP(kRowShr4, 0xf)
     LBL_MIN_PLUS_STEP(kRowShr8, 0xf)
     LBL_MIN_PLUS_STEP(kRowBcast15, 0xa)
+    LBL_MIN_PLUS_STEP(kRowBcast31, 0xc)
 #undef LBL_MIN_PLUS_STEP
 }
 
-constexpr int kScanBlock = 32;      // runs per (min,+) scan
+// Runs per (min,+) scan.  A block ends where a run's first slot is no longer held by every run
+// before it in the block, i.e. after 2*cut_off + 1 = 51 runs of a table in wavenumber order: with
+// 32 lanes the chain of the 4999 runs of the benchmark tables was 157 steps long, with 64 it is
+// 99 (and each step one scan level longer).  Every step is ~330 dependent instructions of a
+// single wavefront that shares its SIMD with accumulate wavefronts: 3.3 us.
+constexpr int kScanBlock = 64;
 // (The chain kernels are single workgroups that start beside a resident accumulate grid, whose
 // workgroups hold 12-27 KB of LDS each, six or seven to a CU: what a chain kernel asks for must
 // fit in what they leave, ~50 KB, or it waits for a CU to drain -- 1.4 ms in a kernel trace when
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
             __builtin_amdgcn_wave_barrier();   // one wavefront: LDS keeps its order
         }
         const int r = b + lane;
-        const bool candidate = lane < kScanBlock && r < staged_to;
+        const bool candidate = r < staged_to;
         RunLink mine;
         mine.ks = mine.ke = 0.;
         mine.mask_s = mine.mask_e = 0;
@@ -566,8 +571,8 @@ __global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restri
             }
         }
         const double a_own = a, c_own = c;
-        static_assert(kScanBlock == 32, "half_wave_min_plus_scan covers lanes 0..31");
-        half_wave_min_plus_scan(a, c);
+        static_assert(kScanBlock == 64, "wave_min_plus_scan covers the wavefront");
+        wave_min_plus_scan(a, c);
         const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
         const double before = dpp_from<kWaveShr1, 0xf>(0., total);     // lane 0 keeps 0
         // P_r = L_r - L_{r-1}; on the branch L_r = L_{r-1} + a it is a itself, exactly.

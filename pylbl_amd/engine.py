@@ -155,6 +155,15 @@ def _f64(array):
     return np.ascontiguousarray(array, dtype=np.float64)
 
 
+def _levels(values):
+    """Per-level input as a contiguous 1-d float64 array (no copy, and none of numpy's dispatch,
+    when it already is one: a call on a small grid costs the host ~35 us all told)."""
+    if type(values) is np.ndarray and values.dtype == np.float64 and values.ndim == 1 and \
+            values.flags.c_contiguous:
+        return values
+    return _f64(np.atleast_1d(values))
+
+
 class DeviceSpectra(object):
     """Spectra left in HBM: [levels, n] float64 on the engine's GPU."""
     def __init__(self, engine, levels, n):
@@ -358,8 +367,7 @@ class Engine(object):
         while the call computes, in `pieces` runs of tiles (lbl_compute_streamed).
         defer_finish: keep the call's last kernels (the ones that touch `out`) back until
         finish_deferred() / synchronize(): LBL_DEFER_FINISH."""
-        t, p, x = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure)), \
-            _f64(np.atleast_1d(vmr))
+        t, p, x = _levels(temperature), _levels(pressure), _levels(vmr)
         if not (t.shape == p.shape == x.shape and t.ndim == 1):
             raise ValueError("temperature, pressure and vmr must be 1-d and equally long.")
         n = (int(vn) - int(v0))*int(n_per_v)
