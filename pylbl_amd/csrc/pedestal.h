@@ -452,10 +452,11 @@ __device__ __forceinline__ void wave_min_plus_scan(double & a, double & c)
 }
 
 // Runs per (min,+) scan.  A block ends where a run's first slot is no longer held by every run
-// before it in the block, i.e. after 2*cut_off + 1 = 51 runs of a table in wavenumber order: with
-// 32 lanes the chain of the 4999 runs of the benchmark tables was 157 steps long, with 64 it is
-// 99 (and each step one scan level longer).  Every step is ~330 dependent instructions of a
-// single wavefront that shares its SIMD with accumulate wavefronts: 3.3 us.
+// before it in the block (after 2*cut_off + 1 = 51 runs of one-run-per-cell tables) or where its
+// last slot is held by some but not all of them -- which is what lines within a pressure shift of
+// an integer wavenumber do: they alternate between two windows, and each alternation ends a block.
+// The benchmark tables (shifts up to 0.01 cm-1 at 1 atm) take ~1 700 steps for their 4 999 cells, so
+// the wider scan buys little there (0.52 -> 0.48 ms); tables without shifts take a tenth of that.
 constexpr int kScanBlock = 64;
 // (The chain kernels are single workgroups that start beside a resident accumulate grid, whose
 // workgroups hold 12-27 KB of LDS each, six or seven to a CU: what a chain kernel asks for must
