@@ -386,6 +386,7 @@ struct lbl_engine
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
+    int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
 
     // Timing.
@@ -930,10 +931,18 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         int lane_index = 0;
         if (alternate)
         {
-            lane_index = (int)(engine->next_lane++ % kLanes);
+            // How many lanes: the runtime maps streams onto four hardware queues, and calls on more
+            // lanes than that only stretch one another's kernels.  Measured (profiles/
+            // r03_ab_lanes.txt): calls with a pedestal pass (two streams each) 4 lanes against 8:
+            // -1 % on the default workload, -8...-12 % with the far-field series; calls on tiny
+            // grids (three short dependent kernels, nothing to overlap but launch gaps) 2 lanes:
+            // 23.6 us per call against 33-35 us on 4 or 8.
+            const int rotate = engine->lanes_in_use > 0 ? engine->lanes_in_use
+                                                        : (pedestal_pass ? 4 : 2);
+            lane_index = (int)(engine->next_lane++ % rotate);
             if (&engine->lanes[lane_index] == engine->deferred)
             {
-                lane_index = (int)(engine->next_lane++ % kLanes);
+                lane_index = (int)(engine->next_lane++ % rotate);
             }
         }
         Lane & lane = engine->lanes[lane_index];
@@ -1747,6 +1756,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
+    }
+    else if (key == "lanes" && (value == 0 || (value >= 2 && value <= kLanes)))
+    {
+        engine->lanes_in_use = (int)value;
     }
     else if (key == "farfield" && (value == 0 || value == 1))
     {
