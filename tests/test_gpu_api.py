@@ -408,6 +408,39 @@ def test_plan_cache_is_bounded_and_results_do_not_depend_on_it(oracle):
     engine.free(handle)
 
 
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+def test_lane_count_changes_nothing(remove_pedestal):
+    """Asynchronous calls rotate over 2 lanes on tiny grids and 4 with a pedestal pass (option
+    lanes = 0), or over what the option says: a burst of calls into a ring of two blocks -- every
+    block is overwritten many times, by calls on different lanes -- ends with the same bits as the
+    blocking call, whatever the number of lanes."""
+    from pylbl_amd.engine import DeviceSpectra, default_engine
+    engine = default_engine(0)
+    tables = [synthetic.line_table("CO2", 600., 700., num_lines=4000, seed=s) for s in (3, 4, 5)]
+    handles = [engine.load(t) for t in tables]
+    v0, vn, npv = 620, 680, 20
+    n = (vn - v0)*npv
+    expected = [engine.compute(h, 240., 3e4, 4e-4, v0, vn, npv, remove_pedestal=remove_pedestal)[0]
+                for h in handles]
+    ring = [DeviceSpectra(engine, 1, n) for _ in range(2)]
+    try:
+        for lanes in (2, 3, 8, 0):
+            engine.set_option("lanes", lanes)
+            for turn in range(24):
+                engine.compute(handles[turn % 3], 240., 3e4, 4e-4, v0, vn, npv, out=ring[turn % 2],
+                               remove_pedestal=remove_pedestal, asynchronous=True)
+            engine.synchronize()
+            # turn 22 wrote ring[0] last (table 22 % 3 = 1), turn 23 ring[1] (table 2)
+            assert np.array_equal(ring[0].to_host()[0], expected[1]), lanes
+            assert np.array_equal(ring[1].to_host()[0], expected[2]), lanes
+    finally:
+        engine.set_option("lanes", 0)
+        for block in ring:
+            block.free()
+        for h in handles:
+            engine.free(h)
+
+
 def test_row_copies_and_pinned_results():
     """lbl_copy_rows_to_host places device rows straight into a strided destination
     (beta[level, mechanism, :]); page-locked result arrays are recycled once dropped."""
