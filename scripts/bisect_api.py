@@ -9,8 +9,20 @@ if "torch" in mode:
     import torch
     if "importonly" not in mode:
         torch.cuda.set_device(0)
-        if "noalloc" not in mode:
+        if "emptyonly" in mode:
+            x = torch.empty(10, device="cuda")
+        elif "synconly" in mode:
+            torch.cuda.synchronize()
+        elif "stream" in mode:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                x = torch.zeros(10, device="cuda")
+            torch.cuda.synchronize()
+        elif "noalloc" not in mode:
             x = torch.zeros(10, device="cuda")
+            if "freed" in mode:
+                del x
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
 from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic
 from pylbl_amd.engine import default_engine, DeviceSpectra
 tables = [synthetic.line_table(f, 1., 5000.) for f in ("H2O", "CO2")]
