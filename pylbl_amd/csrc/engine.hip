@@ -735,9 +735,11 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
     // of combine_kernel (A/B on the 5 M-point workloads: 2-3 % against items half that size).
     // Dense bands still get their heavy tiles cut.  On small grids (a launch does not fill the
     // chip; every scalar load is a miss) short chains of lines per wavefront matter more than the
-    // per-item overhead: items down to 128 lines.
+    // per-item overhead: items down to 128 lines.  (Grids in between -- 0.01 cm-1 over 5000 cm-1,
+    // ~2000 tiles -- do best with at least 1024 lines per item: 0.632 -> 0.622 ms per step against
+    // 512, scripts/experiments/small_sweep.py.)
     const long long floor_lines = engine->item_floor > 0 ? engine->item_floor
-                                  : (n_tiles < 1024 || farfield) ? 128 : 512;
+                                  : (n_tiles < 1024 || farfield) ? 128 : 1024;
     const long long target = std::max<long long>(floor_lines, total/(8*1536) + 1);
     // Streamed calls (lbl_compute_streamed) launch the tiles in `pieces` runs, each followed by
     // the copy of its columns: runs of about equal weight, every tile counted with a floor that
