@@ -917,6 +917,11 @@ def run():
                                          "lanes and their accumulate kernels overlap in time, so "
                                          "avg_launch_ms is not the duration of a kernel running "
                                          "alone (see the plain run for that)")
+        elif n*levels_local <= (1 << 20):
+            line["roofline"]["note"] += ("; a grid of at most 2^20 points x levels: calls alternate "
+                                         "between two engine lanes and their accumulate kernels may "
+                                         "overlap in time, so avg_launch_ms is not the duration of a "
+                                         "kernel running alone")
         if args.host_output:
             line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
         if args.ablate:

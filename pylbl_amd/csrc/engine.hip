@@ -387,6 +387,7 @@ struct lbl_engine
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
+    long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
 
     // Timing.
@@ -913,8 +914,11 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         // pedestal (their serial chain leaves it almost idle) and calls on small grids; plain
         // calls on large grids run back to back on lane 0, behind everything the other lanes
         // hold, as does anything the caller waits for.
-        // Small grids (a launch does not fill the chip, latency rules) gain the same way.
-        const bool small = n_long*rq.n_levels <= (1ll << 16);
+        // Small grids (a launch does not fill the chip, latency rules) gain the same way: up to 2^20
+        // points x levels (BASELINE configs[1], 500 k points: 0.625 -> 0.597 ms per step with four
+        // calls in flight; at 5 M points it is -1 %, and left alone so that a launch's duration
+        // stays what it takes alone).
+        const bool small = n_long*rq.n_levels <= engine->small_points;
         // A call that adds into its output can share the GPU too when it removes the pedestal:
         // only its last kernel (pedestal_apply_kernel) touches the output, everything before
         // works in the lane's own buffers.
@@ -1758,6 +1762,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
+    }
+    else if (key == "small_points" && value >= 0)
+    {
+        engine->small_points = value;
     }
     else if (key == "lanes" && (value == 0 || (value >= 2 && value <= kLanes)))
     {
