@@ -917,8 +917,9 @@ def run():
                                          "lanes and their accumulate kernels overlap in time, so "
                                          "avg_launch_ms is not the duration of a kernel running "
                                          "alone (see the plain run for that)")
-        elif n*levels_local <= (1 << 20):
-            line["roofline"]["note"] += ("; a grid of at most 2^20 points x levels: calls alternate "
+        elif n*levels_local <= (1 << 20) or args.farfield:
+            line["roofline"]["note"] += ("; a grid of at most 2^20 points x levels, or the far-field "
+                                         "series: calls alternate "
                                          "between two engine lanes and their accumulate kernels may "
                                          "overlap in time, so avg_launch_ms is not the duration of a "
                                          "kernel running alone")
