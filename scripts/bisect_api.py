@@ -37,6 +37,9 @@ if "load" in mode:
         for h, t, o in zip(hs, tables, outs):
             e.compute(h, level.t, level.p, level.vmr[t.formula], 1, 5001, 1000, out=o, asynchronous=True)
     e.synchronize()
+if "nullstream" in mode:
+    e.order_stream_after(0)
+    e.synchronize()
 if "timing" in mode:
     e.set_option("timing", 2); e.timing(reset=True); e.set_option("timing", 0)
 if "pool" in mode:
