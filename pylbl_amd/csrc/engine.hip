@@ -670,7 +670,7 @@ int pick_tiling(const lbl_engine * engine, int farfield, int n_per_v, long long 
     {
         // Measured on the 0.001 cm-1 workload: 4 is ~2 % ahead of 8 for the direct kernel,
         // 8 is ahead when the far-field series carries most lines.
-        p = (n_per_v >= 400 && farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 20 ? 2 : 1;
+        p = (n_per_v >= 400 && farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 10 ? 2 : 1;
     }
     tiling.aligned = 0;
     tiling.per_cell = 0;
@@ -737,10 +737,10 @@ Molecule::Plan & plan_for(lbl_engine * engine, int farfield, Molecule & m, const
     // Dense bands still get their heavy tiles cut.  On small grids (a launch does not fill the
     // chip; every scalar load is a miss) short chains of lines per wavefront matter more than the
     // per-item overhead: items down to 128 lines.  (Grids in between -- 0.01 cm-1 over 5000 cm-1,
-    // ~2000 tiles -- do best with at least 1024 lines per item: 0.632 -> 0.622 ms per step against
-    // 512, scripts/experiments/small_sweep.py.)
+    // ~2000 tiles -- do best with at least 2048 lines per item now that their calls take turns on
+    // two lanes: 0.590 -> 0.579 ms per step against 1024, which had been 2 % ahead of 512.)
     const long long floor_lines = engine->item_floor > 0 ? engine->item_floor
-                                  : (n_tiles < 1024 || farfield) ? 128 : 1024;
+                                  : (n_tiles < 1024 || farfield) ? 128 : 2048;
     const long long target = std::max<long long>(floor_lines, total/(8*1536) + 1);
     // Streamed calls (lbl_compute_streamed) launch the tiles in `pieces` runs, each followed by
     // the copy of its columns: runs of about equal weight, every tile counted with a floor that
