@@ -388,8 +388,13 @@ def api_leg(engine, tables, atmos, v_lo, v_hi, dv, device_step_ms, repeats=5):
                        f"continua, host arrays returned", "formats": {},
            "d2h_pinned_gbs_measured": link_gbs}
     for fmt, arrays in (("total", 1), ("gas", len(formulas)), ("all", 3*len(formulas))):
-        for _ in range(4):          # every engine lane and pooled block has been used once
-            spec.compute_absorption(output_format=fmt)
+        # Warm-up the way the timed loop runs: every engine lane and pooled block used once, and
+        # the previous result still alive while the next call computes -- two generations of
+        # page-locked result arrays, or the second timed call pays for pinning one (4.6 / 7.5 /
+        # 19 ms instead of 2.1 / 2.6 / 3.8: a fifth of which was in every mean before round 3's end).
+        result = None
+        for _ in range(4):
+            result = spec.compute_absorption(output_format=fmt)
         start = time.perf_counter()
         for _ in range(repeats):
             result = spec.compute_absorption(output_format=fmt)
