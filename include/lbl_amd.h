@@ -139,8 +139,9 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
  * pre-pass on a side stream, default 1), "scan_chain" (0/1: parallel form of the pedestal
  * chain where it applies, default 1), "farfield" (0/1: distant lines by power series, default
  * 0), "aligned_tiles" (0/1: cell-aligned tiles also without the far-field series), "lanes" (0, 2..8:
- * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "ablate" (timing
- * diagnostics only). */
+ * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "small_points" (grids of
+ * up to so many points x levels count as short calls), "graphs" (0/1: short calls replay a HIP
+ * graph of their kernels; default 0), "ablate" (timing diagnostics only). */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
 /* With option timing=1: accumulated kernel milliseconds and launch counts since the last

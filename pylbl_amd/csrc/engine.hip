@@ -144,8 +144,29 @@ enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal =
 // One in-flight compute call: its own pair of streams and its own workspace, so that
 // several molecules can be in the pipeline at once (the serial pedestal chain of one
 // overlaps the accumulate kernels of the others, and its own).
+// A call on a tiny grid is three short dependent kernels (prologue -> accumulate -> combine) and its
+// cost is their launches: such calls replay an instantiated HIP graph of the three, kept per lane
+// and plan, whose kernel arguments are set afresh every call (engine option graphs).
+struct SmallGraph
+{
+    const void * plan = nullptr;        // Molecule::Plan it was built for (items, split tiles)
+    int count = 0, points = 0;
+    unsigned prologue_blocks = 0, items = 0, combine_blocks = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t prologue = nullptr, accumulate = nullptr, combine = nullptr;
+    void destroy()
+    {
+        if (exec != nullptr) (void)hipGraphExecDestroy(exec);
+        if (graph != nullptr) (void)hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+    }
+};
+
 struct Lane
 {
+    std::vector<SmallGraph> graphs;     // most recently used last, at most 8
     hipStream_t main = nullptr;     // prepare, schedule, accumulate, apply, copies
     hipStream_t side = nullptr;     // the pedestal pre-pass
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
@@ -233,6 +254,8 @@ struct Lane
     void destroy()
     {
         drain();
+        for (auto & graph : graphs) graph.destroy();
+        graphs.clear();
         if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
         pinned_levels = nullptr;
         if (prepared != nullptr) (void)hipEventDestroy(prepared);
@@ -387,6 +410,7 @@ struct lbl_engine
     int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
+    int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
 
@@ -834,6 +858,114 @@ void launch_accumulate(int points, dim3 grid, hipStream_t stream, const Accumula
     HIP_TRY(hipGetLastError());
 }
 
+// Replays (builds at first use) the graph prologue -> accumulate -> combine of a call on a tiny
+// grid with this call's arguments.
+void launch_small_graph(Lane & lane, const Molecule::Plan & plan, const Molecule & m,
+                        LevelScalars * levels, const InlineLevels & packed, const GridSpec & g,
+                        const RangeRule & rule, const Tiling & tiling, int prepare_blocks,
+                        unsigned prologue_blocks, int count, int points,
+                        const AccumulateArgs & args, hipStream_t stream)
+{
+    // The kernels' arguments, in their declared order.
+    LineTableView view = m.view();
+    InlineLevels inline_levels = packed;
+    int use_inline = 1, farfield = 0, blocks = prepare_blocks;
+    GridSpec grid_spec = g;
+    RangeRule range_rule = rule;
+    Tiling tiles = tiling;
+    LineWing * wing = const_cast<LineWing *>(args.wing);
+    LineCore * core = const_cast<LineCore *>(args.core);
+    TileSchedule * schedule = const_cast<TileSchedule *>(args.schedule);
+    double * derived = nullptr;
+    unsigned long long * evals = nullptr;
+    void * prologue_args[] = {&view, &levels, &inline_levels, &use_inline, &grid_spec, &range_rule,
+                              &tiles, &farfield, &blocks, &wing, &core, &schedule, &derived,
+                              &evals};
+    AccumulateArgs accumulate = args;
+    accumulate.items = plan.items.data;
+    void * accumulate_args[] = {&accumulate};
+    AccumulateArgs combine = args;
+    const SplitTile * split = plan.split.data;
+    int n_split = plan.n_split, row_points = 64*points;
+    void * combine_args[] = {&combine, &split, &n_split, &row_points};
+
+    const unsigned items = (unsigned)plan.n_items;
+    const unsigned combine_blocks = plan.n_split > 0 ? (unsigned)((plan.n_split*points + 3)/4) : 0;
+    hipKernelNodeParams node[3] = {};
+    node[0].func = reinterpret_cast<void *>(&prologue_kernel);
+    node[0].gridDim = dim3(prologue_blocks, (unsigned)count);
+    node[0].kernelParams = prologue_args;
+    switch (points)
+    {
+    case 1: node[1].func = reinterpret_cast<void *>(&accumulate_kernel<1>); break;
+    case 2: node[1].func = reinterpret_cast<void *>(&accumulate_kernel<2>); break;
+    case 4: node[1].func = reinterpret_cast<void *>(&accumulate_kernel<4>); break;
+    default: node[1].func = reinterpret_cast<void *>(&accumulate_kernel<8>); break;
+    }
+    node[1].gridDim = dim3(items, (unsigned)count);
+    node[1].kernelParams = accumulate_args;
+    node[2].func = reinterpret_cast<void *>(&combine_kernel);
+    node[2].gridDim = dim3(std::max(combine_blocks, 1u), (unsigned)count);
+    node[2].kernelParams = combine_args;
+    for (auto & n : node)
+    {
+        n.blockDim = dim3(256);
+        n.sharedMemBytes = 0;
+        n.extra = nullptr;
+    }
+
+    SmallGraph * found = nullptr;
+    for (size_t i = 0; i < lane.graphs.size(); ++i)
+    {
+        SmallGraph & c = lane.graphs[i];
+        if (c.plan == &plan && c.count == count && c.points == points &&
+            c.prologue_blocks == prologue_blocks && c.items == items &&
+            c.combine_blocks == combine_blocks)
+        {
+            std::rotate(lane.graphs.begin() + i, lane.graphs.begin() + i + 1, lane.graphs.end());
+            found = &lane.graphs.back();
+            break;
+        }
+    }
+    if (found == nullptr)
+    {
+        if (lane.graphs.size() >= 8)
+        {
+            HIP_TRY(hipStreamSynchronize(stream));      // the oldest graph may still be running
+            lane.graphs.front().destroy();
+            lane.graphs.erase(lane.graphs.begin());
+        }
+        SmallGraph fresh;
+        fresh.plan = &plan;
+        fresh.count = count;
+        fresh.points = points;
+        fresh.prologue_blocks = prologue_blocks;
+        fresh.items = items;
+        fresh.combine_blocks = combine_blocks;
+        HIP_TRY(hipGraphCreate(&fresh.graph, 0));
+        HIP_TRY(hipGraphAddKernelNode(&fresh.prologue, fresh.graph, nullptr, 0, &node[0]));
+        HIP_TRY(hipGraphAddKernelNode(&fresh.accumulate, fresh.graph, &fresh.prologue, 1, &node[1]));
+        if (combine_blocks > 0)
+        {
+            HIP_TRY(hipGraphAddKernelNode(&fresh.combine, fresh.graph, &fresh.accumulate, 1,
+                                          &node[2]));
+        }
+        HIP_TRY(hipGraphInstantiate(&fresh.exec, fresh.graph, nullptr, nullptr, 0));
+        lane.graphs.push_back(fresh);
+        found = &lane.graphs.back();
+    }
+    else
+    {
+        HIP_TRY(hipGraphExecKernelNodeSetParams(found->exec, found->prologue, &node[0]));
+        HIP_TRY(hipGraphExecKernelNodeSetParams(found->exec, found->accumulate, &node[1]));
+        if (combine_blocks > 0)
+        {
+            HIP_TRY(hipGraphExecKernelNodeSetParams(found->exec, found->combine, &node[2]));
+        }
+    }
+    HIP_TRY(hipGraphLaunch(found->exec, stream));
+}
+
 struct ComputeRequest
 {
     int32_t molecule, n_levels;
@@ -1077,6 +1209,14 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             // of it); more go through the pinned block.
             const bool host_prep = engine->prep == LBL_PREP_HOST;
             const bool inline_levels = !host_prep && count <= kInlineLevels;
+            InlineLevels packed;
+            int prepare_blocks = 0;
+            unsigned prologue_blocks = 1;
+            // Tiny grids: the call's three kernels as one replayed graph (SmallGraph).
+            const bool graphed = engine->graphs && alternate && small && !with_pedestal &&
+                                 !farfield && inline_levels && want_k && out_device && !streamed &&
+                                 rq.evals == nullptr && rq.derived == nullptr &&
+                                 chunk >= rq.n_levels && engine->timing == 0 && n_lines > 0;
             if (!inline_levels)
             {
                 HIP_TRY(hipMemcpyAsync(lane.levels.data, lane.pinned_levels,
@@ -1135,14 +1275,15 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
             else
             {
-                InlineLevels packed;
                 if (inline_levels)
                 {
                     std::memcpy(packed.level, lane.pinned_levels, count*sizeof(LevelScalars));
                 }
-                const int prepare_blocks = (int)((n_lines + 255)/256);
+                prepare_blocks = (int)((n_lines + 255)/256);
                 const int schedule_blocks = want_k ? (int)((8ll*n_tiles + 255)/256) : 0;
-                engine->timed(kTimePrepare, stream, [&] {
+                prologue_blocks = (unsigned)std::max(prepare_blocks + schedule_blocks, 1);
+                // (A graphed call launches its prologue with the accumulate kernel, below.)
+                if (!graphed) engine->timed(kTimePrepare, stream, [&] {
                     dim3 grid((unsigned)std::max(prepare_blocks + schedule_blocks, 1),
                               (unsigned)count);
                     hipLaunchKernelGGL(prologue_kernel, grid, dim3(256), 0, stream, m->view(),
@@ -1287,7 +1428,12 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             // All accumulate launches first, back to back; the chain is queued behind the first
             // two of a streamed call (the host waits for the run counts inside), and whatever
             // finishes pieces is queued last.
-            for (int piece = 0; piece < pieces; ++piece)
+            if (graphed)
+            {
+                launch_small_graph(lane, plan, *m, lane.levels.data, packed, g, rule, tiling,
+                                   prepare_blocks, prologue_blocks, count, points, args, stream);
+            }
+            for (int piece = 0; piece < (graphed ? 0 : pieces); ++piece)
             {
                 const int item0 = plan.item_begin[piece], item1 = plan.item_begin[piece + 1];
                 const int split0 = plan.split_begin[piece], split1 = plan.split_begin[piece + 1];
@@ -1766,6 +1912,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
+    }
+    else if (key == "graphs" && (value == 0 || value == 1))
+    {
+        engine->graphs = (int)value;
     }
     else if (key == "small_points" && value >= 0)
     {
