@@ -334,7 +334,7 @@ def lines_leg(engine, handles, tables, t, p, vmr, grid_args, steps, remove_pedes
                 total += result[1]
         return total
     evals = step(count=True)
-    # Asynchronous calls with a pedestal rotate over the engine's eight lanes, each with its own
+    # Asynchronous calls with a pedestal rotate over the engine's lanes (up to eight, option lanes), each with its own
     # workspace allocated at first use: warm all of them up, not only the first few.
     if remove_pedestal or ring > 1:
         warmup = max(warmup, -(-8//len(handles)) + 1)
@@ -754,7 +754,7 @@ def run():
         torch.cuda.synchronize()
 
     evals_per_step_local = count_evals()
-    # (With --pedestal the calls rotate over the engine's eight lanes: their workspaces are
+    # (With --pedestal the calls rotate over the engine's lanes (up to eight, option lanes): their workspaces are
     # allocated at first use, so the warm-up has to reach all of them.)
     warm = max(args.warmup, 1)
     if args.pedestal and not args.host_output:
