@@ -471,49 +471,6 @@ def test_small_calls_as_replayed_graphs_give_the_same_bits():
             engine.free(h)
 
 
-@pytest.mark.parametrize("farfield", [False, True])
-def test_bound_on_pedestal_runs_holds_where_shifts_cross_integers(oracle, farfield):
-    """The pedestal pre-pass sizes its buffers from a bound on the runs (engine.hip:runs_bound), not
-    from the GPU's count.  A table made to strain it: four fifths of the lines within 2e-3 cm-1 of
-    an integer wavenumber, shifts of up to +-0.05 cm-1 per atm at 3 atm -- nearly every line may land
-    on either side of its integer, windows alternate row by row.  Same bits as with the counts read
-    back (option count_runs), and the oracle's values."""
-    import dataclasses
-    from pylbl_amd.engine import default_engine
-    engine = default_engine(0)
-    base = synthetic.line_table("CO2", 600., 660., num_lines=6000, seed=41)
-    rng = np.random.default_rng(42)
-    nu = base.nu.copy()
-    near = rng.random(nu.size) < 0.8
-    nu[near] = np.round(nu[near]) + rng.uniform(-2e-3, 2e-3, int(near.sum()))
-    order = np.argsort(nu, kind="stable")
-    fields = {f.name: getattr(base, f.name) for f in dataclasses.fields(base)}
-    for name in ("nu", "sw", "gamma_air", "gamma_self", "n_air", "elower", "delta_air",
-                 "local_iso_id"):
-        fields[name] = (nu if name == "nu" else fields[name])[order]
-    fields["delta_air"] = rng.uniform(-0.05, 0.05, nu.size)
-    table = type(base)(**fields)
-    handle = engine.load(table)
-    t, p, x = [250., 296.], [3.04e5, 2.0e4], [4e-4, 4e-4]
-    v0, vn, npv = 610, 650, 50
-    try:
-        engine.set_option("count_runs", 1)
-        counted = engine.compute(handle, t, p, x, v0, vn, npv, remove_pedestal=True,
-                                 farfield=farfield).copy()
-        engine.set_option("count_runs", 0)
-        bounded = engine.compute(handle, t, p, x, v0, vn, npv, remove_pedestal=True,
-                                 farfield=farfield)
-        assert np.array_equal(bounded, counted)
-    finally:
-        engine.set_option("count_runs", 0)
-        engine.free(handle)
-    for level in range(2):
-        k_ref, _ = oracle.absorption_port(table, t[level], p[level], x[level], v0, vn, npv,
-                                          remove_pedestal=True)
-        scale = np.max(np.abs(k_ref))
-        assert np.max(np.abs(bounded[level] - k_ref)) <= 1e-6*scale
-
-
 def test_row_copies_and_pinned_results():
     """lbl_copy_rows_to_host places device rows straight into a strided destination
     (beta[level, mechanism, :]); page-locked result arrays are recycled once dropped."""
