@@ -93,11 +93,6 @@ struct Molecule
     // Host copies: row order (for the range rule) and sorted order (host prep, inspection).
     std::vector<double> nu_row;
     bool ascending = true;
-    // Ascending tables: every line's distance to the nearest integer wavenumber, sorted, and the
-    // span of the integer parts -- what bounds the number of pedestal runs without asking the GPU
-    // (runs_bound()).
-    std::vector<double> integer_distance;
-    long long floor_span = 0;
     std::vector<int> order;                 // sorted position -> row
     std::vector<double> column[7];          // sorted: nu, sw, gamma_air, gamma_self, n_air, elower, delta_air
     std::vector<int> iso_slot;              // sorted
@@ -416,8 +411,6 @@ struct lbl_engine
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
-    int count_runs = 0;             // 1: the pedestal pass waits for the GPU's run counts (diagnostics)
-    int early_prepass = 1;          // 0: pedestal pre-pass queued behind the accumulate launches (before round 3)
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
 
@@ -973,22 +966,6 @@ void launch_small_graph(Lane & lane, const Molecule::Plan & plan, const Molecule
     HIP_TRY(hipGraphLaunch(found->exec, stream));
 }
 
-// An upper bound on the runs of the pedestal pass (rows that follow each other with the same
-// window, pedestal.h) for a table in wavenumber order at a level whose pressure shifts stay below
-// `shift`: a row opens a run only if its window differs from the previous row's, windows follow
-// floor(nu + shift_r), and for two rows farther than `shift` from every integer that is floor(nu)
-// -- so at most one run per change of floor(nu) plus two per row that is not (plus two per row
-// without data, which reads as an empty window and ends a run wherever it stands).  0: no bound
-// (rows in arbitrary order: the counts come from the GPU).
-int runs_bound(const Molecule & m, double shift)
-{
-    if (!m.ascending || m.n_lines <= 0) return 0;
-    const long long near = std::upper_bound(m.integer_distance.begin(), m.integer_distance.end(),
-                                            shift + 1.e-9) - m.integer_distance.begin();
-    const long long bound = 4 + m.floor_span + 2*near + 2*(long long)m.bad_rows.size();
-    return (int)std::max<long long>(1, std::min(bound, m.n_lines));
-}
-
 struct ComputeRequest
 {
     int32_t molecule, n_levels;
@@ -1326,7 +1303,6 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             // Its run-finding kernels go first: once the accumulate grid owns the chip their
             // wide workgroups would wait for it to drain.
             hipStream_t ped_stream = engine->overlap_pedestal ? lane.side : stream;
-            int bound_on_runs = 0;
             if (with_pedestal)
             {
                 if (engine->overlap_pedestal)
@@ -1334,40 +1310,14 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                     HIP_TRY(hipEventRecord(lane.prepared, stream));
                     HIP_TRY(hipStreamWaitEvent(lane.side, lane.prepared, 0));
                 }
-                double shift = 0.;
-                for (int l = 0; l < count; ++l)
-                {
-                    shift = std::max(shift, lane.pinned_levels[l].shift_max);
-                }
-                bound_on_runs = engine->count_runs ? 0 : runs_bound(*m, shift);
                 engine->timed(kTimePedestal, ped_stream, [&] {
                     pedestal_find_runs(lane.pedestal, ped_stream, m->view(), lane.wing.data,
-                                       count, bound_on_runs == 0);
+                                       count);
                 }, 0);
                 if (engine->overlap_pedestal)
                 {
                     HIP_TRY(hipEventRecord(lane.runs_found, lane.side));
                 }
-            }
-            // The rest of the pre-pass (run sums, links, the serial chain, the tables).  With a bound
-            // on the runs the host has nothing to wait for and queues it here, ahead of the series and
-            // accumulate launches: the chain starts ~0.1 ms earlier (it is the longest path of a call
-            // with the far-field series: -3 % per step; -2...-3 % on the default workload with the
-            // pedestal too).  Without a bound (rows not in wavenumber order) it follows the accumulate
-            // launches, so that the host waits for the run counts with the GPU busy.
-            bool prepass_queued = false;
-            auto queue_prepass = [&] {
-                engine->timed(kTimePedestal, ped_stream, [&] {
-                    pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
-                                    lane.core.data, g, count, n_cells, engine->scan_chain != 0,
-                                    bound_on_runs);
-                });
-                prepass_queued = true;
-            };
-            if (with_pedestal && bound_on_runs > 0 && engine->overlap_pedestal &&
-                engine->early_prepass)
-            {
-                queue_prepass();
             }
 
             // Where the spectra of this pass end up, and where the accumulate kernel writes.
@@ -1517,7 +1467,10 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             }
             if (with_pedestal)
             {
-                if (!prepass_queued) queue_prepass();
+                engine->timed(kTimePedestal, ped_stream, [&] {
+                    pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
+                                    lane.core.data, g, count, n_cells, engine->scan_chain != 0);
+                });
                 Lane::Finish & f = lane.finish;
                 f.pieces = pieces;
                 f.count = count;
@@ -1749,16 +1702,6 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
         m->tips_q.assign(tips_data, tips_data + (size_t)num_iso*num_t);
         m->nu_row.assign(nu, nu + n_lines);
         m->ascending = std::is_sorted(m->nu_row.begin(), m->nu_row.end());
-        if (m->ascending && n_lines > 0)
-        {
-            m->integer_distance.resize((size_t)n_lines);
-            for (long long j = 0; j < n_lines; ++j)
-            {
-                m->integer_distance[j] = std::fabs(nu[j] - std::round(nu[j]));
-            }
-            std::sort(m->integer_distance.begin(), m->integer_distance.end());
-            m->floor_span = (long long)(std::floor(nu[n_lines - 1]) - std::floor(nu[0]));
-        }
         m->order.resize((size_t)n_lines);
         std::iota(m->order.begin(), m->order.end(), 0);
         if (!m->ascending)
@@ -1969,14 +1912,6 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
-    }
-    else if (key == "early_prepass" && (value == 0 || value == 1))
-    {
-        engine->early_prepass = (int)value;
-    }
-    else if (key == "count_runs" && (value == 0 || value == 1))
-    {
-        engine->count_runs = (int)value;
     }
     else if (key == "graphs" && (value == 0 || value == 1))
     {

@@ -853,7 +853,7 @@ inline void pedestal_check(hipError_t status, const char * what)
 // counts to the host.  The engine orders them before the accumulate launch of the same call
 // (a resident accumulate grid of another call does not hold them up, see kScanThreads).
 inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
-                               const LineWing * wing, int count, bool counts_to_host = true)
+                               const LineWing * wing, int count)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
@@ -869,22 +869,16 @@ inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const
                        t.sorted_of_row, n_lines, n_blocks, ws.block_count.data,
                        ws.run_start.data);
     check(hipGetLastError(), "run scan kernels");
-    if (counts_to_host)
-    {
-        ws.host_counts.resize((size_t)count);
-        check(hipMemcpyAsync(ws.host_counts.data(), ws.run_count.data, count*sizeof(int),
-                             hipMemcpyDeviceToHost, stream), "run count copy");
-    }
+    ws.host_counts.resize((size_t)count);
+    check(hipMemcpyAsync(ws.host_counts.data(), ws.run_count.data, count*sizeof(int),
+                         hipMemcpyDeviceToHost, stream), "run count copy");
 }
 
-// Second half: sums, links, chain and tables on `stream`; leaves cell_sum / point_sum for
-// pedestal_apply_kernel.  The kernels read the run counts on the device; the host only needs a
-// capacity per level: `runs_bound` if the caller has one (engine.hip: for tables in wavenumber
-// order a run can only begin where the integer part of a line position changes or a pressure
-// shift may carry a line across an integer), else the counts themselves, which it waits for.
+// Second half: waits for the run counts, then sums, links, chain and tables on `stream`;
+// leaves cell_sum / point_sum for pedestal_apply_kernel.
 inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                             const LineWing * wing, const LineCore * core, const GridSpec & g,
-                            int count, int n_cells, bool scan_chain = true, int runs_bound = 0)
+                            int count, int n_cells, bool scan_chain = true)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
@@ -893,12 +887,9 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     ws.bin_sum.reserve((size_t)count*n_bins);
     ws.cell_sum.reserve((size_t)count*n_cells);
     ws.point_sum.reserve((size_t)count*n_cells);
-    int max_runs = std::max(runs_bound, 1);
-    if (runs_bound <= 0)
-    {
-        check(hipStreamSynchronize(stream), "run count sync");
-        for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
-    }
+    check(hipStreamSynchronize(stream), "run count sync");
+    int max_runs = 1;
+    for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
     ws.runs.reserve((size_t)count*max_runs);
     ws.slot_sums.reserve((size_t)count*max_runs*slot_stride);
     hipLaunchKernelGGL(run_sums_kernel, dim3(std::min(max_runs, 65535), count), dim3(64), 0,
