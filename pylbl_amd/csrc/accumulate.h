@@ -20,8 +20,16 @@
 //                        eight lines per reciprocal;
 //   [a1,f1) and [f2,a2): the same, and far enough away for the optional power series of
 //                        farfield.h (empty, f1 = a1 and f2 = a2, when that is off);
-//   [lo,a1), [c1,c2), [a2,hi): anything else -> per-line, per-64-point-row decisions
-//                        (window clipping, exact reference region chain near the core).
+//   [c1,c2):             the tile may hold points of the line's core -> core_lines(): per line
+//                        a bit mask of the rows that lie wholly in w4 region 1 (one rational
+//                        function, no selection), of the rows that may hold core points (the
+//                        reference's region chain lane by lane) and of the rest (far wing); the
+//                        inner points (|x| < xlim1) of all of them in a pass of their own,
+//                        inner_ranges();
+//   [lo,a1) and [a2,hi): the window ends inside the tile -> clipped_ranges(): eight lines with
+//                        the same window as one far-wing group with the row masked; what does not
+//                        group, and the 0-3 left-over lines of the fast ranges, line by line
+//                        (general_line).
 // Work is handed out as WorkItems (a tile, or a share of a heavy tile's lines), heaviest first.
 #pragma once
 
