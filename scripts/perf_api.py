@@ -18,6 +18,9 @@ surface = synthetic.surface_level()
 level = synthetic.Atmos(p=surface.p, t=surface.t, vmr={f: surface.vmr[f] for f in
                                                         ("H2O", "CO2")})
 grid = np.arange(1., 5000., 0.001)
+if os.environ.get("LANES"):
+    from pylbl_amd.engine import default_engine
+    default_engine(0).set_option("lanes", int(os.environ["LANES"]))
 for farfield in (True, False):
     spec = Spectroscopy(level, grid, MemoryDatabase(tables), farfield=farfield)
     for count in pieces:
