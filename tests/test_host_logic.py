@@ -250,3 +250,16 @@ def test_partition_function_object_checks_its_shape():
     assert tips.total_partition_function(101.25, 1) == pytest.approx(4.)
     # An exact table temperature takes the interval below it (the reference's left-sided search).
     assert tips.total_partition_function(101., 1) == pytest.approx(3.)
+
+
+def test_level_arrays_pass_through_without_a_copy():
+    """Engine.compute takes per-level values as they come: a contiguous 1-d float64 array is used
+    as it is (no numpy dispatch on the 20 us path of a small call), anything else is converted."""
+    from pylbl_amd.engine import _levels
+    ready = np.asarray([250., 260.])
+    assert _levels(ready) is ready
+    for other in (250., [250., 260.], np.asarray([250, 260]), np.asarray([1., 2., 3., 4.])[::2],
+                  np.float32(250.)):
+        made = _levels(other)
+        assert made.dtype == np.float64 and made.ndim == 1 and made.flags.c_contiguous
+        assert np.array_equal(made, np.atleast_1d(np.asarray(other, dtype=np.float64)))
