@@ -1,7 +1,9 @@
 """Benchmark of the molecular-lines hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ...
+     bench.py --gpus N ... -- or bare: without WORLD_SIZE in the environment bench.py starts its
+     N ranks itself as child processes, before anything touches the GPU: launch_ranks)
 
 A step = one pass of the hot path over one batch: for every (level, molecule) unit of this
 rank (pylbl_amd.distributed.partition), line-scalar prep + tile schedule + Voigt accumulate
@@ -92,6 +94,9 @@ def parse():
     parser.add_argument("--exchange-timeout", type=float, default=180.,
                         help="N > 1: seconds any collection of spectra, barrier or reduction may "
                              "take before the rank reports what it was waiting for and exits 3")
+    parser.add_argument("--launch-timeout", type=float, default=1500.,
+                        help="bare `bench.py --gpus N` (no launcher, N > 1): seconds the N child "
+                             "ranks may take before they are ended and the run reported failed")
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
@@ -575,6 +580,95 @@ def device_identity(torch, index):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: starts the N ranks as CHILD
+    processes (what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1` would start: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, one process per GPU), relays rank 0's JSON line on stdout and the other
+    ranks' output on stderr, and returns the worst exit code.  The first rank that fails ends
+    the others (a rank blocked in a collective cannot be woken), and so do --launch-timeout
+    and a signal to this process.  Called before torch is imported or HIP touched: a process
+    that holds a GPU must never start or become another program."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(port), "GROUP_RANK": "0", "ROLE_RANK": "0", "NODE_RANK": "0",
+                 "PYLBL_BENCH_LAUNCHER": "bench.py"})
+    base.setdefault("OMP_NUM_THREADS", "1")             # as torch.distributed.run does
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs here
+    command = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    children, relays = [], []
+
+    def relay(stream, target, prefix):
+        for text in stream:
+            target.write(prefix + text)
+            target.flush()
+
+    for rank in range(n):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        child = subprocess.Popen(command, env=env, stdout=subprocess.PIPE, text=True,
+                                 start_new_session=True, cwd=os.getcwd())
+        children.append(child)
+        target, prefix = (sys.stdout, "") if rank == 0 else (sys.stderr, f"[rank {rank}] ")
+        thread = threading.Thread(target=relay, args=(child.stdout, target, prefix), daemon=True)
+        thread.start()
+        relays.append(thread)
+
+    def stop(sig):
+        for child in children:
+            if child.poll() is None:
+                try:
+                    os.killpg(child.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(number, frame):
+        stop(signal.SIGTERM)
+        time.sleep(2.)
+        stop(signal.SIGKILL)
+        os._exit(128 + number)
+    for number in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(number, on_signal)
+
+    deadline = time.monotonic() + args.launch_timeout
+    reason = None
+    while True:
+        codes = [child.poll() for child in children]
+        if all(code is not None for code in codes):
+            break
+        failed = [r for r, code in enumerate(codes) if code not in (None, 0)]
+        if failed:
+            reason = f"rank {failed[0]} left with code {codes[failed[0]]}"
+        elif time.monotonic() > deadline:
+            reason = f"no result after --launch-timeout {args.launch_timeout:g} s"
+        if reason:
+            time.sleep(5.)                    # let the others print what they were doing
+            stop(signal.SIGTERM)
+            time.sleep(3.)
+            stop(signal.SIGKILL)
+            for child in children:
+                child.wait()
+            break
+        time.sleep(0.05)
+    for thread in relays:
+        thread.join(timeout=5.)
+    codes = [child.returncode for child in children]
+    worst = max((128 - code if code < 0 else code) for code in codes)
+    if reason:
+        print(json.dumps({"bench_failed": True, "launcher": True, "reason": reason,
+                          "exit_codes": codes}), file=sys.stderr, flush=True)
+        worst = worst or 1
+    return worst
+
+
 def main():
     """Runs the benchmark; a rank that fails says which rank it is and what it was doing, then
     leaves with a non-zero code so that the launcher stops the others (a rank blocked in a
@@ -611,9 +705,12 @@ def run():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.
+        # Nothing here has touched HIP or imported torch yet, and it never will -- the ranks
+        # are children, this process only relays their output and exit code.
+        raise SystemExit(launch_ranks(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
         args.gpus = world
 
     import torch
@@ -847,6 +944,9 @@ def run():
             },
             "distributed": None if world == 1 else {
                 "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "launcher": os.environ.get("PYLBL_BENCH_LAUNCHER") or (
+                    "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                    else "environment"),
                 "distinct_devices": len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id"),
                                           r.get("device_index")) for r in everyone}),
                 "ranks_sharing_a_device": shared,

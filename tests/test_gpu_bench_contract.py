@@ -15,8 +15,8 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
         "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
-def run(command):
-    result = subprocess.run(command, capture_output=True, text=True, cwd=ROOT, timeout=600)
+def run(command, env=None):
+    result = subprocess.run(command, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert result.returncode == 0, result.stderr[-3000:]
     lines = [x for x in result.stdout.strip().splitlines() if x.startswith("{")]
     assert len(lines) == 1, result.stdout[-2000:]
@@ -50,14 +50,24 @@ def test_single_gpu_line():
     assert line["pedestal_option"]["value"] > 1.e9
 
 
-def test_two_rank_line():
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "bench.py"])
+def test_two_rank_line(launcher):
+    """Under the launcher the driver's contract names, and bare (`python bench.py --gpus 2`):
+    bench.py then starts its two ranks itself, as children, before anything touches the GPU."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
-                "--backend", "gloo", "--config", "1", "--steps", "2", "--warmup", "1"])
+    arguments = ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "1", "--steps", "2",
+                 "--warmup", "1"]
+    if launcher == "bench.py":
+        environment = {k: v for k, v in os.environ.items()
+                       if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        line = run([sys.executable] + arguments, env=environment)
+    else:
+        line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                    "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + arguments)
     check(line, 2, 2, 1)
+    assert line["distributed"]["launcher"] == launcher
     assert "cpu_baseline" not in line           # rank 0 at N = 1 only
     assert line["config"]["levels_total"] == 2
     # What makes the first RCCL run on the driver's node diagnosable: who ran where, each rank's

@@ -263,3 +263,29 @@ def test_level_arrays_pass_through_without_a_copy():
         made = _levels(other)
         assert made.dtype == np.float64 and made.ndim == 1 and made.flags.c_contiguous
         assert np.array_equal(made, np.atleast_1d(np.asarray(other, dtype=np.float64)))
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_worst_exit_code():
+    """`python bench.py --gpus 2` with no launcher around it starts two child ranks (before it
+    imports torch or touches HIP), relays what they print and leaves with the worst of their exit
+    codes plus one JSON diagnostic.  Without a GPU both ranks refuse to run: that refusal, the
+    diagnostic and the exit code are what this checks (the GPU twin is
+    tests/test_gpu_bench_contract.py::test_two_rank_line[bench.py])."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: the ranks would run the benchmark")
+    environment = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    result = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo",
+                             "--steps", "1", "--warmup", "0", "--launch-timeout", "120"],
+                            capture_output=True, text=True, cwd=ROOT, env=environment, timeout=300)
+    assert result.returncode == 1
+    assert result.stdout.strip() == ""                 # no result line from a run that failed
+    refusals = [x for x in result.stderr.splitlines() if "needs an MI355X" in x]
+    assert len(refusals) == 2
+    report = json.loads([x for x in result.stderr.splitlines() if x.startswith("{")][-1])
+    assert report["bench_failed"] and report["launcher"] and report["exit_codes"] == [1, 1]
