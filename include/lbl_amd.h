@@ -17,9 +17,22 @@
  *
  * Conventions: plain C types only; every function returns LBL_OK (0) or a non-zero
  * status and never throws; the message for the last failure on a handle is available
- * from lbl_last_error(); a handle may be used from one thread at a time (distinct
- * handles are independent).  All arrays are caller-owned; "host" pointers are ordinary
+ * from lbl_last_error().  All arrays are caller-owned; "host" pointers are ordinary
  * process memory, "device" pointers are HIP device allocations on the engine's GPU.
+ *
+ * Threads: every entry point may be called from any number of threads on the SAME handle at
+ * once, as the reference's absorption() may (no globals or statics, absorption.c:19-99; ctypes
+ * releases the GIL around it, gas_optics.py:79-91).  A handle serialises the host side of its
+ * calls -- queueing work is microseconds -- with a mutex of its own; a blocking call waits for
+ * its result after it has released that mutex, so other threads' calls queue up behind it on
+ * the GPU meanwhile, and each call returns exactly what it would have returned alone.
+ * lbl_last_error() returns the calling thread's own last message.  What stays with the caller:
+ * output blocks that several asynchronous calls share (LBL_ACCUMULATE) see those calls in the
+ * order they were made, so threads that add into ONE block without ordering themselves get the
+ * sum in a nondeterministic order of additions; and there is one deferred call per handle
+ * (LBL_DEFER_FINISH) -- a pipeline that defers should not share its handle with other threads
+ * while it does (pylbl_amd.Spectroscopy holds a lock per engine for that).  Distinct handles
+ * are independent.
  */
 #ifndef LBL_AMD_H_
 #define LBL_AMD_H_
@@ -71,8 +84,10 @@ typedef struct lbl_engine lbl_engine;
 int lbl_engine_create(int device, lbl_engine **engine);
 int lbl_engine_destroy(lbl_engine *engine);
 
-/* Message of the last failure on this handle ("" if none); engine may be NULL to read the
- * message of a failed lbl_engine_create on the calling thread. */
+/* Message of the calling thread's last failure on this handle (of the handle's last failure
+ * if this thread has had none; "" if none); engine may be NULL to read the message of a failed
+ * lbl_engine_create on the calling thread.  The pointer stays valid until the calling thread's
+ * next failure or next call of this function. */
 const char *lbl_last_error(const lbl_engine *engine);
 
 /* Uploads one molecule: replaces the per-call SQLite row loop of absorption.c:44-86
@@ -122,6 +137,12 @@ int lbl_compute_streamed(lbl_engine *engine, int32_t molecule, int32_t n_levels,
  * LBL_DEFER_FINISH could not be honoured and which therefore finished at once. */
 int lbl_finish_deferred(lbl_engine *engine);
 int lbl_deferred(const lbl_engine *engine);
+/* Drops what a call kept back instead of queueing it: the call's target block and host range
+ * are then never written by it (what it queued before works in buffers of the engine).  For
+ * hosts that fail between a deferred call and its lbl_finish_deferred and are about to release
+ * the block.  lbl_device_free, lbl_host_free, lbl_copy_to_host, lbl_copy_rows_to_host and
+ * lbl_order_stream_after_engine finish a deferred call first (like lbl_synchronize). */
+int lbl_cancel_deferred(lbl_engine *engine);
 
 /* Waits for everything enqueued on the engine (all of its streams); a deferred call is finished
  * first. */

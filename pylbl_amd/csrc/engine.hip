@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -36,6 +37,10 @@ namespace {
 using namespace lbl;
 
 thread_local std::string g_create_error;
+// The message of the calling thread's last failure and the handle it belongs to: what
+// lbl_last_error returns, so that a thread never reads a message another thread is writing.
+thread_local std::string g_thread_error;
+thread_local const void * g_thread_error_engine = nullptr;
 
 struct HipFailure
 {
@@ -385,6 +390,13 @@ struct SpectralGrid
 
 struct lbl_engine
 {
+    // Every entry point of the C ABI that takes this handle holds the mutex while it reads or
+    // changes the engine's host-side state (lanes, plans, workspaces, write records, options) and
+    // queues its work; the GPU work itself runs asynchronously.  The reference's absorption() has
+    // no state at all (absorption.c:19-99) and ctypes releases the GIL around it
+    // (gas_optics.py:79-91), so any number of threads may call it at once: so may they here.
+    // (Recursive: lbl_synchronize finishes a deferred call through the public entry.)
+    std::recursive_mutex mutex;
     int device = 0;
     hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
     hipStream_t copy_stream = nullptr;  // results on their way to host memory
@@ -562,6 +574,15 @@ struct lbl_engine
         deferred = nullptr;
     }
 
+    // Drops what a call kept back instead of queueing it (lbl_cancel_deferred): its target block
+    // and host range are never touched by that call.  What it has queued already works in the
+    // lane's own buffers only.
+    void cancel_deferred()
+    {
+        if (deferred != nullptr) deferred->finish.pending = false;
+        deferred = nullptr;
+    }
+
     // Orders `stream` (lane 0's) behind everything queued on the other lanes so far, without
     // stopping the host: what a call that adds into its output, or reuses lane 0 after calls
     // that rotated over the lanes, needs.
@@ -581,9 +602,21 @@ namespace {
 
 int fail(lbl_engine * engine, int code, const std::string & message)
 {
-    if (engine != nullptr) engine->error = message; else g_create_error = message;
+    if (engine != nullptr)
+    {
+        std::lock_guard<std::recursive_mutex> guard(engine->mutex);
+        engine->error = message;
+        g_thread_error = message;
+        g_thread_error_engine = engine;
+    }
+    else
+    {
+        g_create_error = message;
+    }
     return code;
 }
+
+typedef std::lock_guard<std::recursive_mutex> EngineLock;
 
 Molecule * find_molecule(lbl_engine * engine, int32_t handle)
 {
@@ -982,7 +1015,10 @@ struct ComputeRequest
     int32_t pieces = 1;
 };
 
-int compute(lbl_engine * engine, const ComputeRequest & rq)
+// wait_for: where a blocking call (no LBL_ASYNC) leaves an event behind its last operation instead
+// of waiting for it -- the caller waits after it has released the engine's mutex, so that other
+// threads queue their calls meanwhile.  nullptr: wait here.
+int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_for = nullptr)
 {
     Molecule * m = find_molecule(engine, rq.molecule);
     if (m == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "unknown molecule handle.");
@@ -1065,9 +1101,15 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         const bool alternate = (rq.flags & LBL_ASYNC) && want_k && rq.derived == nullptr &&
                                ((pedestal_pass && (!add_into_block || out_device)) ||
                                 ((small || short_kernels) && out_device && !add_into_block));
-        if (!alternate || (rq.flags & LBL_DEFER_FINISH))
+        if ((rq.flags & LBL_DEFER_FINISH) ||
+            (!alternate && engine->deferred == &engine->lanes[0]))
         {
-            // Lane 0's ordering covers every lane, and there is one deferral at a time.
+            // There is one deferral at a time; and a call about to reuse lane 0's buffers must not
+            // find a kept-back call still needing them.  (Kept-back calls stay off lane 0, below,
+            // so a plain call -- another thread's, say -- leaves a deferral alone: the order in
+            // which a pipeline's calls add into their block does not depend on who else uses the
+            // engine.  The kept-back kernels order themselves behind every write of their block
+            // when they are queued, run_finish.)
             engine->finish_deferred();
         }
         int lane_index = 0;
@@ -1082,7 +1124,8 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
             const int rotate = engine->lanes_in_use > 0 ? engine->lanes_in_use
                                                         : (pedestal_pass ? 4 : 2);
             lane_index = (int)(engine->next_lane++ % rotate);
-            if (&engine->lanes[lane_index] == engine->deferred)
+            if (&engine->lanes[lane_index] == engine->deferred ||
+                (lane_index == 0 && (rq.flags & LBL_DEFER_FINISH)))
             {
                 lane_index = (int)(engine->next_lane++ % rotate);
             }
@@ -1523,7 +1566,11 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
                     HIP_TRY(hipMemcpyAsync(rq.k + base*stride, lane.staging.data,
                                            (size_t)count*n_long*8, hipMemcpyDeviceToHost,
                                            stream));
-                    HIP_TRY(hipStreamSynchronize(stream));
+                    // (The last pass's copy is waited for at the end of the call.)
+                    if (base + count < rq.n_levels || (rq.flags & LBL_ASYNC))
+                    {
+                        HIP_TRY(hipStreamSynchronize(stream));
+                    }
                 }
                 else
                 {
@@ -1581,7 +1628,15 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         }
         if (!(rq.flags & LBL_ASYNC))
         {
-            HIP_TRY(hipStreamSynchronize(stream));
+            if (wait_for != nullptr)
+            {
+                *wait_for = engine->take_event();
+                HIP_TRY(hipEventRecord(*wait_for, stream));
+            }
+            else
+            {
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
         }
     }
     catch (const HipFailure & f)
@@ -1597,6 +1652,28 @@ int compute(lbl_engine * engine, const ComputeRequest & rq)
         return fail(engine, LBL_ERROR, e.what());
     }
     return LBL_OK;
+}
+
+// compute() under the engine's mutex; the wait of a blocking call outside it.
+int locked_compute(lbl_engine * engine, const ComputeRequest & rq)
+{
+    hipEvent_t last = nullptr;
+    int status;
+    {
+        EngineLock lock(engine->mutex);
+        status = compute(engine, rq, &last);
+    }
+    if (last != nullptr)
+    {
+        const hipError_t waited = hipEventSynchronize(last);
+        EngineLock lock(engine->mutex);
+        engine->event_pool.push_back(last);
+        if (waited != hipSuccess && status == LBL_OK)
+        {
+            status = fail(engine, LBL_ERROR, hipGetErrorString(waited));
+        }
+    }
+    return status;
 }
 
 }  // namespace
@@ -1644,6 +1721,12 @@ int lbl_engine_create(int device, lbl_engine ** engine)
 int lbl_engine_destroy(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_OK;
+    {
+        // (Whoever destroys a handle has made sure no other thread still uses it; the lock only
+        // lets calls that are on their way out leave.)
+        EngineLock lock(engine->mutex);
+        engine->cancel_deferred();
+    }
     (void)hipSetDevice(engine->device);
     engine->drain_lanes();
     for (auto & s : engine->spans)
@@ -1666,7 +1749,18 @@ int lbl_engine_destroy(lbl_engine * engine)
 
 const char * lbl_last_error(const lbl_engine * engine)
 {
-    return engine != nullptr ? engine->error.c_str() : g_create_error.c_str();
+    if (engine == nullptr) return g_create_error.c_str();
+    if (g_thread_error_engine != engine)
+    {
+        // No failure of this thread on this handle yet: the handle's last message, copied under
+        // the lock into this thread's own string (the pointer stays valid until the thread's
+        // next failure or next call of this function).
+        lbl_engine * e = const_cast<lbl_engine *>(engine);
+        EngineLock lock(e->mutex);
+        g_thread_error = e->error;
+        g_thread_error_engine = engine;
+    }
+    return g_thread_error.c_str();
 }
 
 int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
@@ -1678,6 +1772,7 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
                       int32_t * molecule)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     if (molecule == nullptr || n_lines < 0 || n_lines > 0x7fffffff || mass == nullptr ||
         tips_temperature == nullptr || tips_data == nullptr || num_iso < 1 || num_t < 2 ||
         (n_lines > 0 && (nu == nullptr || sw == nullptr || gamma_air == nullptr ||
@@ -1772,6 +1867,7 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
 int lbl_molecule_free(lbl_engine * engine, int32_t molecule)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     if (find_molecule(engine, molecule) == nullptr)
     {
         return fail(engine, LBL_BAD_ARGUMENT, "unknown molecule handle.");
@@ -1793,7 +1889,7 @@ int lbl_compute(lbl_engine * engine, int32_t molecule, int32_t n_levels,
     if (evals != nullptr) *evals = 0;
     ComputeRequest rq{molecule, n_levels, temperature, pressure, vmr, v0, vn, n_per_v, cut_off,
                       remove_pedestal, range_policy, flags, k, level_stride, evals, nullptr};
-    return compute(engine, rq);
+    return locked_compute(engine, rq);
 }
 
 int lbl_compute_streamed(lbl_engine * engine, int32_t molecule, int32_t n_levels,
@@ -1804,6 +1900,7 @@ int lbl_compute_streamed(lbl_engine * engine, int32_t molecule, int32_t n_levels
                          int64_t columns, int32_t pieces)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     if (k == nullptr || host == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "k or host is NULL.");
     if (!(flags & LBL_OUT_DEVICE))
     {
@@ -1834,6 +1931,7 @@ int lbl_line_scalars(lbl_engine * engine, int32_t molecule, double temperature,
                      double * derived)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     if (derived == nullptr) return fail(engine, LBL_BAD_ARGUMENT, "derived is NULL.");
     (void)remove_pedestal;
     ComputeRequest rq{molecule, 1, &temperature, &pressure, &vmr, v0, vn, n_per_v, cut_off,
@@ -1843,13 +1941,23 @@ int lbl_line_scalars(lbl_engine * engine, int32_t molecule, double temperature,
 
 int lbl_deferred(const lbl_engine * engine)
 {
-    return (engine != nullptr && engine->deferred != nullptr && engine->deferred->finish.pending)
-           ? 1 : 0;
+    if (engine == nullptr) return 0;
+    EngineLock lock(const_cast<lbl_engine *>(engine)->mutex);
+    return (engine->deferred != nullptr && engine->deferred->finish.pending) ? 1 : 0;
+}
+
+int lbl_cancel_deferred(lbl_engine * engine)
+{
+    if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
+    engine->cancel_deferred();
+    return LBL_OK;
 }
 
 int lbl_finish_deferred(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
@@ -1865,6 +1973,7 @@ int lbl_finish_deferred(lbl_engine * engine)
 int lbl_synchronize(lbl_engine * engine)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     (void)hipSetDevice(engine->device);
     // A call still kept back (LBL_DEFER_FINISH) is finished first: nothing stays unapplied.
     const int finished = lbl_finish_deferred(engine);
@@ -1955,6 +2064,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
 int lbl_timing(lbl_engine * engine, double ms[8], int64_t launches[8], int32_t reset)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
@@ -1989,9 +2099,13 @@ void * lbl_stream(lbl_engine * engine)
 int lbl_order_stream_after_engine(lbl_engine * engine, void * stream)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
+        // "Everything queued so far" includes what a call kept back (LBL_DEFER_FINISH): the
+        // caller's stream is about to read the block.
+        engine->finish_deferred();
         hipStream_t theirs = reinterpret_cast<hipStream_t>(stream);
         // Side streams end in an event their lane's main stream waits for (pedestal_done), so
         // the main streams and the copy stream stand for everything the engine has queued.
@@ -2013,6 +2127,7 @@ int lbl_order_stream_after_engine(lbl_engine * engine, void * stream)
 int lbl_order_engine_after_stream(lbl_engine * engine, void * stream)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
@@ -2043,7 +2158,11 @@ int lbl_device_alloc(lbl_engine * engine, int64_t bytes, void ** pointer)
 int lbl_device_free(lbl_engine * engine, void * pointer)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     (void)hipSetDevice(engine->device);
+    // A call kept back (LBL_DEFER_FINISH) may still have this block to write: it is finished
+    // first, like in lbl_synchronize -- never left to run into freed memory.
+    try { engine->finish_deferred(); } catch (const HipFailure &) { engine->cancel_deferred(); }
     engine->drain_lanes();
     hipError_t status = hipFree(pointer);
     if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));
@@ -2056,7 +2175,10 @@ int lbl_copy_to_host(lbl_engine * engine, void * host, const void * device, int6
     {
         return LBL_BAD_ARGUMENT;
     }
+    EngineLock lock(engine->mutex);
     (void)hipSetDevice(engine->device);
+    try { engine->finish_deferred(); }
+    catch (const HipFailure & f) { return fail(engine, LBL_ERROR, f.message); }
     // The memory may have been written on any lane (asynchronous calls with a pedestal rotate
     // over them): wait for all of them, not only for lane 0.
     hipError_t status = hipSuccess;
@@ -2078,6 +2200,7 @@ int lbl_fill_zero(lbl_engine * engine, double * k, int32_t n_levels, int64_t n,
                   int64_t level_stride, int32_t flags)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     if (k == nullptr || n_levels < 0 || n < 0 || (level_stride != 0 && level_stride < n))
     {
         return fail(engine, LBL_BAD_ARGUMENT, "lbl_fill_zero: bad argument.");
@@ -2092,8 +2215,16 @@ int lbl_fill_zero(lbl_engine * engine, double * k, int32_t n_levels, int64_t n,
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
-        // Ordered like a plain compute call: after everything queued on the other lanes.
-        for (int i = 1; i < kAllLanes; ++i) engine->lanes[i].drain();
+        // Ordered like a plain compute call: after everything queued on the other lanes --
+        // by events when the caller does not wait either, so that the host keeps queueing.
+        if (flags & LBL_ASYNC)
+        {
+            engine->join_lanes(engine->stream);
+        }
+        else
+        {
+            for (int i = 1; i < kAllLanes; ++i) engine->lanes[i].drain();
+        }
         HIP_TRY(hipMemset2DAsync(k, (size_t)stride*8, 0, (size_t)n*8, (size_t)n_levels,
                                  engine->stream));
         engine->lanes[0].note_write(k, ((long long)(n_levels - 1)*stride + n)*8, engine->stream);
@@ -2116,9 +2247,11 @@ int lbl_copy_rows_to_host(lbl_engine * engine, void * host, int64_t host_pitch,
         return LBL_BAD_ARGUMENT;
     }
     if (rows == 0 || row_bytes == 0) return LBL_OK;
+    EngineLock lock(engine->mutex);
     try
     {
         HIP_TRY(hipSetDevice(engine->device));
+        engine->finish_deferred();      // the rows may be what a call kept back still has to write
         // The rows may have been written on any lane: the copy stream waits for what each of
         // them holds now, then copies beside whatever is queued afterwards.
         for (auto & lane : engine->lanes)
@@ -2151,7 +2284,14 @@ int lbl_host_alloc(lbl_engine * engine, int64_t bytes, void ** pointer)
 int lbl_host_free(lbl_engine * engine, void * pointer)
 {
     if (engine == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
     (void)hipSetDevice(engine->device);
+    if (engine->deferred != nullptr && engine->deferred->finish.pending)
+    {
+        // The copies of a streamed call kept back may target this memory.
+        try { engine->finish_deferred(); } catch (const HipFailure &) { engine->cancel_deferred(); }
+        engine->drain_lanes();
+    }
     if (engine->copy_stream != nullptr) (void)hipStreamSynchronize(engine->copy_stream);
     hipError_t status = hipHostFree(pointer);
     if (status != hipSuccess) return fail(engine, LBL_ERROR, hipGetErrorString(status));

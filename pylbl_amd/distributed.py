@@ -215,11 +215,13 @@ class Pending(object):
                     raise self._late(timeout) from error
                 if done is False:
                     raise self._late(timeout)
-        elif self.requests:
+        else:
             import torch
             # An nccl work object only orders the *current torch stream of its device* behind
             # the transfer: name the device (the caller's current device may be another one)
             # and settle that stream with an event that can be polled against the deadline.
+            # (Also with nothing to send or receive: the rank's own blocks were copied into the
+            # collected array on that stream, and the engine overwrites them two calls later.)
             stream = torch.cuda.current_stream(self.device)
             with torch.cuda.device(self.device):
                 for request in self.requests:
@@ -258,9 +260,17 @@ class ShardedLines(object):
                the engine's streams and torch's); None: `flush` is used instead.
         zero: Callable (tensor) that zero-fills a block in the order `compute` works in
               (for_engine: the engine's own fill); None: torch fills and the host waits.
+        order_on_device: None (default; $PYLBL_AMD_ORDER_ON_DEVICE=1 turns it on): `order` is
+              used when the exchange stays on the device (nccl), `flush` otherwise.  True: `order`
+              whenever the blocks are on a device.
+
+    Memory on the receiving rank: the collected array ([L, n] for "total", [molecules, L, n] for
+    "gas") is allocated once and kept; together with that rank's own blocks (two sets, used in
+    turn) BASELINE config 5 in "gas" mode needs 164 GB + 2 x 20.5 GB of its 288 GB, "total" mode
+    20.5 GB + 2 x 2.6 GB.
     """
     def __init__(self, compute, molecules, n, weights=None, group=None, device="cpu",
-                 flush=None, order=None, zero=None):
+                 flush=None, order=None, zero=None, order_on_device=None):
         self.compute = compute
         self.molecules = list(molecules)
         self.n = int(n)
@@ -270,13 +280,21 @@ class ShardedLines(object):
         self.flush = flush
         self.order = order
         self.zero = zero
+        # None: the kernels and the exchange are ordered on the device (no host wait) exactly
+        # when the exchange stays in HBM (nccl).  True: also when the blocks travel through host
+        # memory (gloo on a GPU) -- the staging copies then wait, on torch's stream, for the
+        # engine's events: a rehearsal of the RCCL path's ordering on fewer GPUs than ranks.
+        if order_on_device is None:
+            import os
+            order_on_device = True if os.environ.get("PYLBL_AMD_ORDER_ON_DEVICE") == "1" else None
+        self.order_on_device = order_on_device
         self._buffers = {}
         self._turn = 0
         self.last_exchange = None       # the Pending of the latest call with world > 1
 
     @classmethod
     def for_engine(cls, engine, handles, grid_args, remove_pedestal=False, scale_density=False,
-                   range_policy="reference", weights=None, group=None):
+                   range_policy="reference", weights=None, group=None, order_on_device=None):
         """Per-rank compute on an MI355X: the engine writes spectra straight into torch CUDA
         tensors (torch only owns the memory and runs the exchange).
 
@@ -308,14 +326,16 @@ class ShardedLines(object):
         def zero(tensor):
             engine.fill_zero(Slot(tensor), asynchronous=True)
         return cls(compute, list(handles), n, weights=weights, group=group, device=device,
-                   flush=engine.synchronize, order=order, zero=zero)
+                   flush=engine.synchronize, order=order, zero=zero,
+                   order_on_device=order_on_device)
 
     # -- buffers -----------------------------------------------------------------------------
-    def _buffer(self, name, shape, zero=False):
+    def _buffer(self, name, shape, zero=False, sets=2):
         """Per-rank blocks are kept between calls, two of each so that an exchange still in
-        flight (async_op) is not overwritten by the next call."""
+        flight (async_op) is not overwritten by the next call (sets=1: one, for what only the
+        exchange itself writes)."""
         import torch
-        key = (name, self._turn % 2, tuple(shape))
+        key = (name, self._turn % sets, tuple(shape))
         tensor = self._buffers.get(key)
         if tensor is None:
             tensor = torch.empty(shape, dtype=torch.float64, device=self.device)
@@ -351,9 +371,12 @@ class ShardedLines(object):
 
         Returns:
             On rank `dst` (every rank if dst is None) the result, elsewhere None (dict of None
-            for "gas"); or a Pending that yields it.  With one rank the tensors returned are the
-            rank's own blocks, of which there are two sets used in turn: they keep their contents
-            until the call after next (copy what must live longer).
+            for "gas"); or a Pending that yields it.  The tensors returned are buffers this
+            object keeps and writes again: with one rank the rank's own blocks, of which there are
+            two sets used in turn (contents valid until the call after next); with several ranks
+            the collected array, of which there is ONE (contents valid until the next call's
+            exchange -- wait for a Pending and use or copy its result before calling run() again;
+            successive exchanges are ordered on the exchange library's stream).
         """
         import torch
         import torch.distributed as dist
@@ -411,9 +434,11 @@ class ShardedLines(object):
             if self.flush is not None:
                 self.flush()
             return result
-        if on_device and not through_host and self.order is not None:
+        if on_device and self.order is not None and \
+                (not through_host or self.order_on_device):
             # RCCL: the exchange is queued behind the kernels on the device; the host goes on
-            # (to the next call's kernels: compute k+1 runs beside exchange k).
+            # (to the next call's kernels: compute k+1 runs beside exchange k).  (Rehearsed with
+            # gloo under order_on_device: the staging copies below wait on torch's stream.)
             self.order()
         elif self.flush is not None:
             self.flush()
@@ -429,7 +454,7 @@ class ShardedLines(object):
         i_receive = rank in receivers
         if output == "total" and plan.mode == "units":
             # The molecules of one level sit on several ranks: a real sum over ranks.
-            partial = self._buffer("reduce", (n_levels, n)) if where != "cpu" else \
+            partial = self._buffer("reduce", (n_levels, n), sets=1) if where != "cpu" else \
                 torch.empty((n_levels, n), dtype=torch.float64)
             partial.zero_()
             for i, level in enumerate(my_levels):
@@ -451,14 +476,15 @@ class ShardedLines(object):
             return pending if async_op else pending.wait()
 
         # Grouped point-to-point gather: every block goes straight into its final place.
-        # The collected array is kept between calls like the per-rank blocks (two of each, used
-        # in turn): "gas" output of BASELINE config 5 is 164 GB on the receiving rank.
+        # The collected array is kept between calls -- ONE of it: "gas" output of BASELINE config
+        # 5 is 164 GB on the receiving rank, two would not fit its 288 GB (successive exchanges
+        # write it in the order they were started; see run()'s Returns).
         def collected(shape):
             if not i_receive:
                 return None
             if where == "cpu":
                 return torch.empty(shape, dtype=torch.float64)
-            return self._buffer("final", shape)
+            return self._buffer("final", shape, sets=1)
         if output == "total":
             final = collected((n_levels, n))
             pieces = lambda r: [(None, plan.levels_of(r))]                      # noqa: E731

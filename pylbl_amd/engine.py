@@ -7,6 +7,7 @@ library is missing or no MI355X is visible, creating an Engine raises.
 from ctypes import CDLL, POINTER, Structure, byref, c_char_p, c_double, c_int32, c_int64, \
                    c_void_p
 from pathlib import Path
+import threading
 import weakref
 
 import numpy as np
@@ -25,7 +26,7 @@ RANGE_POLICIES = {"reference": RANGE_REFERENCE, "skip": RANGE_SKIP}
 EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
     "lbl_molecule_free", "lbl_compute", "lbl_compute_streamed", "lbl_finish_deferred",
-    "lbl_deferred", "lbl_synchronize", "lbl_set_option", "lbl_timing",
+    "lbl_deferred", "lbl_cancel_deferred", "lbl_synchronize", "lbl_set_option", "lbl_timing",
     "lbl_stream", "lbl_order_stream_after_engine", "lbl_order_engine_after_stream",
     "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
@@ -109,6 +110,7 @@ def library():
                                                                     c_int64, c_int64, c_int32]
     lib.lbl_finish_deferred.argtypes = [c_void_p]
     lib.lbl_deferred.argtypes = [c_void_p]
+    lib.lbl_cancel_deferred.argtypes = [c_void_p]
     lib.lbl_synchronize.argtypes = [c_void_p]
     lib.lbl_set_option.argtypes = [c_void_p, c_char_p, c_int64]
     lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
@@ -216,28 +218,32 @@ class DevicePool(object):
         self.limit = limit
         self.idle = {}          # shape -> [DeviceSpectra]
         self.idle_bytes = 0
+        self.lock = threading.RLock()       # blocks are taken and given by any thread
 
     def take(self, levels, n):
         shape = (int(levels), int(n))
-        blocks = self.idle.get(shape)
-        if blocks:
-            self.idle_bytes -= shape[0]*shape[1]*8
-            return blocks.pop()
+        with self.lock:
+            blocks = self.idle.get(shape)
+            if blocks:
+                self.idle_bytes -= shape[0]*shape[1]*8
+                return blocks.pop()
         return DeviceSpectra(self.engine(), *shape)
 
     def give(self, block):
         size = block.shape[0]*block.shape[1]*8
-        if not block.pointer or self.idle_bytes + size > self.limit:
-            block.free()
-            return
-        self.idle.setdefault(tuple(block.shape), []).append(block)
-        self.idle_bytes += size
+        with self.lock:
+            if block.pointer and self.idle_bytes + size <= self.limit:
+                self.idle.setdefault(tuple(block.shape), []).append(block)
+                self.idle_bytes += size
+                return
+        block.free()
 
     def clear(self):
-        for blocks in self.idle.values():
+        with self.lock:
+            idle, self.idle, self.idle_bytes = self.idle, {}, 0
+        for blocks in idle.values():
             for block in blocks:
                 block.free()
-        self.idle, self.idle_bytes = {}, 0
 
 
 class PinnedPool(object):
@@ -249,21 +255,25 @@ class PinnedPool(object):
         self.limit = limit
         self.idle = []          # (capacity, pointer)
         self.idle_bytes = 0
+        # Arrays are handed out to any thread and come back from whichever thread drops the last
+        # view (a finalizer: it may run inside array() on the same thread, hence re-entrant).
+        self.lock = threading.RLock()
 
     def array(self, shape):
         shape = tuple(int(x) for x in shape)
         count = int(np.prod(shape)) if shape else 1
         nbytes = max(count*8, 8)
         engine = self.engine()
-        best = None
-        for i, (capacity, _) in enumerate(self.idle):
-            if nbytes <= capacity <= 2*nbytes + (1 << 20) and \
-                    (best is None or capacity < self.idle[best][0]):
-                best = i
-        if best is not None:
-            capacity, pointer = self.idle.pop(best)
-            self.idle_bytes -= capacity
-        else:
+        with self.lock:
+            best = None
+            for i, (capacity, _) in enumerate(self.idle):
+                if nbytes <= capacity <= 2*nbytes + (1 << 20) and \
+                        (best is None or capacity < self.idle[best][0]):
+                    best = i
+            if best is not None:
+                capacity, pointer = self.idle.pop(best)
+                self.idle_bytes -= capacity
+        if best is None:
             capacity, handle = nbytes, c_void_p()
             if engine.lib.lbl_host_alloc(engine.handle, capacity, byref(handle)) != LBL_OK:
                 # No more page-locked memory to be had (results held by the caller count):
@@ -282,18 +292,20 @@ class PinnedPool(object):
         engine = pool.engine() if pool is not None else None
         if engine is None or not engine.handle:
             return                      # engine gone: the runtime reclaims the pages at exit
-        if pool.idle_bytes + capacity <= pool.limit:
-            pool.idle.append((capacity, pointer))
-            pool.idle_bytes += capacity
-        else:
-            engine.lib.lbl_host_free(engine.handle, c_void_p(pointer))
+        with pool.lock:
+            if pool.idle_bytes + capacity <= pool.limit:
+                pool.idle.append((capacity, pointer))
+                pool.idle_bytes += capacity
+                return
+        engine.lib.lbl_host_free(engine.handle, c_void_p(pointer))
 
     def clear(self):
         engine = self.engine()
-        for _, pointer in self.idle:
+        with self.lock:
+            idle, self.idle, self.idle_bytes = self.idle, [], 0
+        for _, pointer in idle:
             if engine is not None and engine.handle:
                 engine.lib.lbl_host_free(engine.handle, c_void_p(pointer))
-        self.idle, self.idle_bytes = [], 0
 
 
 class Engine(object):
@@ -309,6 +321,11 @@ class Engine(object):
         self.device = int(device)
         self.pinned = PinnedPool(self)
         self.blocks = DevicePool(self)
+        # Held by callers whose result takes SEVERAL calls on this engine that must not be
+        # interleaved with another thread's (Spectroscopy.compute_absorption: calls that add into
+        # one block in a fixed order, one deferred call per engine).  Single calls need no lock:
+        # the C ABI serialises them per handle (include/lbl_amd.h, "Threads").
+        self.pipeline = threading.RLock()
 
     def host_array(self, shape):
         """float64 array of the given shape in page-locked host memory (recycled, see
@@ -440,6 +457,11 @@ class Engine(object):
         """True while a call is kept back (False right after a call whose defer_finish could
         not be honoured: no pedestal pass, several level passes, host output)."""
         return bool(self.lib.lbl_deferred(self.handle))
+
+    def cancel_deferred(self):
+        """Drops what a call with defer_finish=True kept back: its `out` block and `deliver`
+        array are never written by it (for callers that fail before finish_deferred())."""
+        self._check(self.lib.lbl_cancel_deferred(self.handle))
 
     def synchronize(self):
         self._check(self.lib.lbl_synchronize(self.handle))
@@ -600,10 +622,12 @@ class Engine(object):
 
 
 _default_engines = {}
+_default_engines_lock = threading.Lock()
 
 
 def default_engine(device=0):
-    """Process-wide engine per device (what Gas objects share)."""
-    if device not in _default_engines:
-        _default_engines[device] = Engine(device)
-    return _default_engines[device]
+    """Process-wide engine per device (what Gas objects share, from any thread)."""
+    with _default_engines_lock:
+        if device not in _default_engines:
+            _default_engines[device] = Engine(device)
+        return _default_engines[device]

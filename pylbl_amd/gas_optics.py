@@ -117,7 +117,18 @@ class Gas(object):
             # spectrum (absorption.c:41, :53-59), so a caller's buffer must read zero as well
             # (nothing is added to one that is being accumulated into).
             if out is not None:
-                return out if accumulate else self.engine.fill_zero(out, asynchronous)
+                if not accumulate:
+                    self.engine.fill_zero(out, asynchronous)
+                if deliver is not None:
+                    # The caller was promised the block's first columns in `deliver`: zeros, or
+                    # (accumulating) whatever the block holds once the calls queued so far have run.
+                    if not hasattr(out, "to_host_into"):
+                        raise ValueError("deliver needs a device `out`.")
+                    if accumulate:
+                        out.to_host_into(deliver, deliver.shape[1], asynchronous=asynchronous)
+                    else:
+                        deliver[...] = 0.
+                return out
             return np.zeros((levels, (vn - v0)*n_per_v))
         return self.engine.compute(self.molecule, temperature, pressure, volume_mixing_ratio,
                                    v0, vn, n_per_v, cut_off=cut_off,

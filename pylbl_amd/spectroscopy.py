@@ -14,6 +14,7 @@ this image) -- without it the atmosphere is a plain (p, t, vmr) tuple and the re
 of numpy arrays with the same variable names.
 """
 from collections import namedtuple
+import contextlib
 
 import numpy as np
 
@@ -309,19 +310,18 @@ class Spectroscopy(object):
                     (continua_here[0].engine if continua_here else cross.engine)
             present.append((name, gas, continua_here, cross))
         # "total" (one block for everything): the gas with the most transitions is queued FIRST and
-        # finished LAST.  Its lines call is the longest (with the pedestal removed it ends in a serial
-        # chain), so everything it does
-        # in buffers of its own -- prologue, far-field series, accumulate, pedestal pre-pass --
-        # starts at once and runs beside the other gases' calls, while the kernels that touch its
-        # block, and the copies that hand that block to the host piece by piece, are kept back
-        # (LBL_DEFER_FINISH) until the others have been queued: it stays the last to add into a
-        # shared block, and its copies queue up behind the other gases' copies, not in front of
-        # them.  (Units are independent, spectroscopy.py:166,179; results are reported in the
-        # atmosphere's order.)
-        # Per-gas blocks ("gas", "all") are the other way round: the link to the host is the
-        # bottleneck there (one block per gas to copy), so the lightest gas goes first -- its block
-        # is complete early and travels beside the kernels of the others -- and the heaviest last,
-        # delivering its block piece by piece while it computes (profiles/r03_ab_api.txt).
+        # finished LAST.  Its lines call is the longest (with the pedestal removed it ends in a
+        # serial chain), so everything it does in buffers of its own -- prologue, far-field series,
+        # accumulate, pedestal pre-pass -- starts at once and runs beside the other gases' calls,
+        # while the kernels that touch its block, and the copies that hand that block to the host
+        # piece by piece, are kept back (LBL_DEFER_FINISH) until the others have been queued: it
+        # stays the last to add into a shared block, and its copies queue up behind the other gases'
+        # copies, not in front of them.  (Units are independent, spectroscopy.py:166,179; results
+        # are reported in the atmosphere's order.) Per-gas blocks ("gas", "all") are the other way
+        # round: the link to the host is the bottleneck there (one block per gas to copy), so the
+        # lightest gas goes first -- its block is complete early and travels beside the kernels of
+        # the others -- and the heaviest last, delivering its block piece by piece while it computes
+        # (profiles/r03_ab_api.txt).
         present.sort(key=lambda entry: entry[1].num_lines if entry[1] is not None else -1)
         heavy = present[-1] if present and present[-1][1] is not None else None
         if heavy is not None and mode == "total":
@@ -351,99 +351,120 @@ class Spectroscopy(object):
                                               out=cross_sum.buffer, accumulate=cross_sum.take(),
                                               asynchronous=True)
 
-        if not in_hbm:
-            for name, gas, continua_here, cross in present:
-                # Too large to keep: one host block per mechanism, summed by numpy below.
-                if gas is not None:
-                    blocks[(name, 0)] = gas.absorption_coefficients(
-                        temperature, pressure, mole_fractions[name], self.grid,
-                        remove_pedestal=remove_pedestal, range_policy=range_policy,
-                        scale_density=True, farfield=self.farfield)[:, :columns]
-                for continuum in continua_here:
-                    values = continuum.spectra_levels(temperature, pressure, mole_fractions,
-                                                      self.grid)
-                    blocks[(name, 1)] = blocks[(name, 1)] + values if (name, 1) in blocks \
-                        else values
-                if cross is not None:
-                    blocks[(name, 2)] = cross.absorption_coefficients(
-                        self.grid, temperature, pressure,
-                        volume_mixing_ratio=mole_fractions[name])
-        elif mode == "total" and present:
-            # Every gas adds into one block.  The heavy gas's slot kernels go first (the first of
-            # them writes the block -- or the engine clears it), then its lines call, kept back;
-            # the other gases' lines with their short continuum and cross-section kernels behind
-            # them; then the heavy gas's last kernels and the delivery of the finished block.
-            total = _Sum(engine, levels, n)
-            results["total"] = engine.host_array((levels, columns))
-            kept_back = False
-            for index, (name, gas, continua_here, cross) in enumerate(present):
-                if heavy is not None and index == 0:
-                    slots_into(name, continua_here, cross, total, total)
-                    if not total.written:
-                        engine.fill_zero(total.buffer, asynchronous=True)
-                        total.take()
-                    lines_into(name, gas, total, deliver=results["total"], defer=True)
-                    kept_back = engine.deferred()
-                    continue
-                if gas is not None:
-                    lines_into(name, gas, total)
-                slots_into(name, continua_here, cross, total, total)
-            if heavy is not None and kept_back:
-                engine.finish_deferred()
-                in_flight.append(total)
-            else:
-                # (No gas with lines -- or a call the engine could not keep back, e.g. without a
-                # pedestal pass: it added at once and delivered a block that was not complete;
-                # this copy, queued behind everything, is the one that counts.)
-                in_flight.append(total.into(results["total"]))
-        else:
-            for index, (name, gas, continua_here, cross) in enumerate(present):
-                last = index + 1 == len(present)
-                if mode == "gas":
-                    block = _Sum(engine, levels, n)
-                    results[name] = engine.host_array((levels, columns))
-                    if gas is not None and last:
-                        slots_into(name, continua_here, cross, block, block)
-                        lines_into(name, gas, block, deliver=results[name])
-                        in_flight.append(block)
-                    else:
+        # Everything from the first queued call to the final wait is one pipeline on the engine:
+        # calls add into shared blocks in a fixed order and one of them may be kept back, so
+        # another thread's calls must not come in between (Engine.pipeline; single calls from
+        # other threads -- Gas.absorption_coefficient -- only wait for their turn).  If anything
+        # fails on the way, what the engine still holds for this call is dropped and waited for
+        # BEFORE the blocks and page-locked arrays go back to their pools: a call kept back
+        # (LBL_DEFER_FINISH) would otherwise apply itself, and copy, into recycled memory the next
+        # time the engine is synchronized.
+        with (engine.pipeline if engine is not None else contextlib.nullcontext()):
+            try:
+                if not in_hbm:
+                    for name, gas, continua_here, cross in present:
+                        # Too large to keep: one host block per mechanism, summed by numpy below.
                         if gas is not None:
-                            lines_into(name, gas, block)
-                        slots_into(name, continua_here, cross, block, block)
-                        # This gas's block goes home while the next gas computes: one copy,
-                        # from HBM straight into its place in a page-locked result.
-                        in_flight.append(block.into(results[name]))
-                    continue
-                values = engine.host_array([levels, len(MECHANISMS), columns])
-                results[name] = values
-                continuum_sum = _Sum(engine, levels, n) if continua_here else None
-                cross_sum = _Sum(engine, levels, n) if cross is not None else None
-                if continua_here or cross is not None:
-                    slots_into(name, continua_here, cross, continuum_sum, cross_sum)
-                for slot, block in ((1, continuum_sum), (2, cross_sum)):
-                    if block is None:
-                        # An empty mechanism slot reads zero (40 MB per level at 5 M points):
-                        # filled by a helper thread beside the queueing and the kernels.
-                        zero_fills.append(values[:, slot, :])
+                            blocks[(name, 0)] = gas.absorption_coefficients(
+                                temperature, pressure, mole_fractions[name], self.grid,
+                                remove_pedestal=remove_pedestal, range_policy=range_policy,
+                                scale_density=True, farfield=self.farfield)[:, :columns]
+                        for continuum in continua_here:
+                            values = continuum.spectra_levels(temperature, pressure, mole_fractions,
+                                                              self.grid)
+                            blocks[(name, 1)] = blocks[(name, 1)] + values if (name, 1) in blocks \
+                                else values
+                        if cross is not None:
+                            blocks[(name, 2)] = cross.absorption_coefficients(
+                                self.grid, temperature, pressure,
+                                volume_mixing_ratio=mole_fractions[name])
+                elif mode == "total" and present:
+                    # Every gas adds into one block.  The heavy gas's slot kernels go first (the
+                    # first of them writes the block -- or the engine clears it), then its lines
+                    # call, kept back; the other gases' lines with their short continuum and cross-
+                    # section kernels behind them; then the heavy gas's last kernels and the
+                    # delivery of the finished block.
+                    total = _Sum(engine, levels, n)
+                    results["total"] = engine.host_array((levels, columns))
+                    kept_back = False
+                    for index, (name, gas, continua_here, cross) in enumerate(present):
+                        if heavy is not None and index == 0:
+                            slots_into(name, continua_here, cross, total, total)
+                            if not total.written:
+                                engine.fill_zero(total.buffer, asynchronous=True)
+                                total.take()
+                            lines_into(name, gas, total, deliver=results["total"], defer=True)
+                            kept_back = engine.deferred()
+                            continue
+                        if gas is not None:
+                            lines_into(name, gas, total)
+                        slots_into(name, continua_here, cross, total, total)
+                    if heavy is not None and kept_back:
+                        engine.finish_deferred()
+                        in_flight.append(total)
                     else:
-                        in_flight.append(block.into(values[:, slot, :]))
-                if gas is None:
-                    zero_fills.append(values[:, 0, :])
+                        # (No gas with lines -- or a call the engine could not keep back, e.g.
+                        # without a pedestal pass: it added at once and delivered a block that was
+                        # not complete; this copy, queued behind everything, is the one that
+                        # counts.)
+                        in_flight.append(total.into(results["total"]))
                 else:
-                    lines_sum = _Sum(engine, levels, n)
-                    if last:
-                        lines_into(name, gas, lines_sum, deliver=values[:, 0, :])
-                        in_flight.append(lines_sum)
-                    else:
-                        lines_into(name, gas, lines_sum)
-                        in_flight.append(lines_sum.into(values[:, 0, :]))
-        filler = _zero_in_background(zero_fills)
-        if engine is not None:
-            engine.synchronize()
-        if filler is not None:
-            filler.join()
-        for block in in_flight:
-            engine.blocks.give(block.buffer)
+                    for index, (name, gas, continua_here, cross) in enumerate(present):
+                        last = index + 1 == len(present)
+                        if mode == "gas":
+                            block = _Sum(engine, levels, n)
+                            results[name] = engine.host_array((levels, columns))
+                            if gas is not None and last:
+                                slots_into(name, continua_here, cross, block, block)
+                                lines_into(name, gas, block, deliver=results[name])
+                                in_flight.append(block)
+                            else:
+                                if gas is not None:
+                                    lines_into(name, gas, block)
+                                slots_into(name, continua_here, cross, block, block)
+                                # This gas's block goes home while the next gas computes: one copy,
+                                # from HBM straight into its place in a page-locked result.
+                                in_flight.append(block.into(results[name]))
+                            continue
+                        values = engine.host_array([levels, len(MECHANISMS), columns])
+                        results[name] = values
+                        continuum_sum = _Sum(engine, levels, n) if continua_here else None
+                        cross_sum = _Sum(engine, levels, n) if cross is not None else None
+                        if continua_here or cross is not None:
+                            slots_into(name, continua_here, cross, continuum_sum, cross_sum)
+                        for slot, block in ((1, continuum_sum), (2, cross_sum)):
+                            if block is None:
+                                # An empty mechanism slot reads zero (40 MB per level at 5 M
+                                # points): filled by a helper thread beside the queueing and the
+                                # kernels.
+                                zero_fills.append(values[:, slot, :])
+                            else:
+                                in_flight.append(block.into(values[:, slot, :]))
+                        if gas is None:
+                            zero_fills.append(values[:, 0, :])
+                        else:
+                            lines_sum = _Sum(engine, levels, n)
+                            if last:
+                                lines_into(name, gas, lines_sum, deliver=values[:, 0, :])
+                                in_flight.append(lines_sum)
+                            else:
+                                lines_into(name, gas, lines_sum)
+                                in_flight.append(lines_sum.into(values[:, 0, :]))
+                filler = _zero_in_background(zero_fills)
+                if engine is not None:
+                    engine.synchronize()
+                if filler is not None:
+                    filler.join()
+                for block in in_flight:
+                    engine.blocks.give(block.buffer)
+            except BaseException:
+                if engine is not None:
+                    try:
+                        engine.cancel_deferred()
+                        engine.synchronize()
+                    except Exception:       # the first error is the one to report
+                        pass
+                raise
 
         if mode == "total":
             values = results.get("total")
