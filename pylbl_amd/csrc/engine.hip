@@ -419,7 +419,7 @@ struct lbl_engine
     int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
-    int scan_chain = 1;             // (min,+) scan for the pedestal chain where windows are monotone
+    int scan_chain = 1;             // pedestal chain by relaxation (pedestal.h), serial chain behind it
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels

@@ -60,11 +60,14 @@ struct alignas(16) RunLink
 {
     double ks;          // GS + VS: first-slot candidate before subtracting earlier pedestals
     double ke;          // GE + VE: last-slot candidate
-    unsigned long long mask_s;  // bit j: run r-1-j holds this run's first slot in its window
-    unsigned long long mask_e;  // bit j: run r-1-j holds this run's last slot
-    int bin, pad0;
-    long long pad1;
+    unsigned long long mask_s[2];   // bit j of word h: run r-1-j-64h holds this run's first slot
+    unsigned long long mask_e[2];   // ... this run's last slot
+    int bin;            // the run's window (RunMeta::bin)
+    int next_same;      // the next run with the same bin, -1 if none
+    int n_slots;
+    int first_of_bin;   // 1: no earlier run has this bin
 };
+static_assert(sizeof(RunLink) == 64, "RunLink");
 
 template <typename T>
 struct RawBuffer
@@ -97,8 +100,9 @@ struct PedestalWorkspace
     RawBuffer<RunMeta> runs;        // [levels][max_runs]
     RawBuffer<double> slot_sums;    // [levels][max_runs][slot_stride]
     RawBuffer<RunLink> links;       // [levels][max_runs]
+    RawBuffer<double> pedestals[2]; // [levels][max_runs]: the relaxation's two sets of values
     RawBuffer<int> prefix_last;     // [levels][max_runs]
-    RawBuffer<int> regular;         // [levels] 1: monotone windows, fast chain
+    RawBuffer<int> state;           // [levels][kChainState], see run_prefix_kernel
     RawBuffer<double> slots;        // [levels][cells+1]       (only when LDS is too small)
     RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]
     RawBuffer<double> cell_sum;     // [levels][cells]
@@ -110,7 +114,8 @@ inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cu
 {
     const long long stride = 2*cut_off + 3;
     const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2));
-    return n_lines*4 + runs*((long long)sizeof(RunMeta) + stride*8) + 4ll*(n_cells + stride)*8;
+    return n_lines*4 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 24) +
+           4ll*(n_cells + stride)*8;
 }
 
 // A row opens a run when its window is not empty and differs from the previous row's
@@ -221,6 +226,17 @@ __device__ __forceinline__ int slot_point(int slot, int n_cells, int n_per_v, in
 
 // One wavefront per run (grid-stride over runs): evaluates every row of the run on the
 // run's slots (lane = slot) with the same profile code the accumulate kernel uses.
+// The rows of a run are taken 64 at a time: lane i fetches row i's records (index, LineWing,
+// LineCore: three dependent loads, side by side for 64 rows) into LDS, then every lane walks the
+// staged rows in the reference's row order.  (Walking the rows straight from HBM put those three
+// round trips on every row: 80-130 us for the benchmark's tables, most of it waiting.)
+struct StagedRow
+{
+    double centre, g2, bl;
+    double repwid, y, amp;
+    int first, last, core_first, core_last;
+};
+
 __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restrict__ wing,
                                                       const LineCore * __restrict__ core,
                                                       const int * __restrict__ sorted_of_row,
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                                                       RunMeta * __restrict__ runs,
                                                       double * __restrict__ slot_sums)
 {
+    __shared__ StagedRow staged[64];
     const int level = blockIdx.y;
     const int lane = threadIdx.x;
     const int count = run_count[level];
@@ -247,9 +264,12 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
         const bool extra = (last_int*g.n_per_v != head.last);
         const int n_slots = last_int - first_slot + 1 + (extra ? 1 : 0);
         double * sums = slot_sums + ((long long)level*max_runs + run)*slot_stride;
+        // Slots of this lane in the passes q0 = 0, 64, ... (one pass unless cut_off > 30).
+        const int passes = (n_slots + 63)/64;
         double vs = 0., ve = 0.;
-        for (int q0 = 0; q0 < n_slots; q0 += 64)
+        for (int pass = 0; pass < passes; ++pass)
         {
+            const int q0 = pass*64;
             const int q = q0 + lane;
             const bool active = q < n_slots;
             const int slot = (extra && q == n_slots - 1) ? n_cells : first_slot + q;
@@ -259,34 +279,52 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
             const bool holds_first = (q0 == 0);
             const bool holds_last = (q0 + 64 >= n_slots);
             double total = 0.;
-            for (int r = row_begin; r < row_end; ++r)
+            bool open = true;
+            for (int base = row_begin; base < row_end && open; base += 64)
             {
-                const int j = sorted_of_row[r];
-                const LineWing l = w[j];
-                if (l.first != head.first || l.last != head.last)
+                const int rows = min(64, row_end - base);
+                __builtin_amdgcn_wave_barrier();    // the previous batch has been read
+                if (lane < rows)
                 {
-                    break;      // an empty or different window ends the run
+                    const int j = sorted_of_row[base + lane];
+                    const LineWing l = w[j];
+                    const LineCore k = c[j];
+                    StagedRow row;
+                    row.centre = l.centre; row.g2 = l.g2; row.bl = l.bl;
+                    row.repwid = k.repwid; row.y = k.y; row.amp = k.amp;
+                    row.first = l.first; row.last = l.last;
+                    row.core_first = k.core_first; row.core_last = k.core_last;
+                    staged[lane] = row;
                 }
-                const LineCore k = c[j];
-                const double d = v - l.centre;
-                double value;
-                if (point < k.core_first || point > k.core_last)
+                __builtin_amdgcn_wave_barrier();    // one wavefront: LDS keeps program order
+                for (int r = 0; r < rows; ++r)
                 {
-                    value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-                }
-                else
-                {
-                    value = k.amp*wells_profile(d*k.repwid, k.y);
-                }
-                total += value;
-                if (holds_first)
-                {
-                    const double at_first = __shfl(value, 0, 64);
-                    vs += at_first;
-                }
-                if (holds_last)
-                {
-                    ve += __shfl(value, n_slots - 1 - q0, 64);
+                    const StagedRow l = staged[r];
+                    if (l.first != head.first || l.last != head.last)
+                    {
+                        open = false;
+                        break;      // an empty or different window ends the run
+                    }
+                    const double d = v - l.centre;
+                    double value;
+                    if (point < l.core_first || point > l.core_last)
+                    {
+                        value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                    }
+                    else
+                    {
+                        value = l.amp*wells_profile(d*l.repwid, l.y);
+                    }
+                    total += value;
+                    if (holds_first)
+                    {
+                        const double at_first = __shfl(value, 0, 64);
+                        vs += at_first;
+                    }
+                    if (holds_last)
+                    {
+                        ve += __shfl(value, n_slots - 1 - q0, 64);
+                    }
                 }
             }
             if (active) sums[q] = total;
@@ -310,25 +348,31 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast chain: the recurrence in the pedestals alone.
+// The recurrence in the pedestals alone, solved by relaxation (round 4).
 //
 // The value accumulated on a slot c before run r is
 //     sum_{q<r, c in W_q} G_q[c]  -  sum_{q<r, c in W_q} P_q
 // (G: profile sums of run q on its slots, W_q its window, P_q the sum of its pedestals), so
-//     P_r = min( GS_r + VS_r - sum_{q<r} P_q [fs_r in W_q] ,  GE_r + VE_r - sum_{q<r} P_q [ls_r in W_q] )
-// with fs_r / ls_r the run's end slots and VS / VE its own end values.  Which earlier runs
-// hold a slot, and the G sums, do not depend on the pedestals: run_links_kernel finds them in
-// parallel (bit masks over the previous 64 runs).  What is left is a recurrence in the P's.
-// Take a block of consecutive runs in which every earlier in-block run holds the later runs'
-// first slots, and holds either all or none of their last slots.  With L_r the in-block
-// prefix sum of P,
-//     L_r = min(Ks_r, L_{r-1} + Ke_r)     (no in-block run holds the last slot), or
-//     L_r = min(Ks_r, Ke_r)               (all of them do),
-// Ks/Ke being the candidates minus the pedestals of covering runs BEFORE the block: a first-
-// order recurrence in the (min,+) semiring, i.e. one wavefront scan per block of up to 32
-// runs instead of one serial step per run.  Blocks end where the pattern breaks (a window
-// that steps backwards: a few dozen places in a 5 000-window spectrum).  Levels where some
-// slot is shared by runs more than 64 apart (rows far out of order) keep run_chain_kernel.
+//     P_r = min( Ks_r - sum_{q<r} P_q [fs_r in W_q] ,  Ke_r - sum_{q<r} P_q [ls_r in W_q] )
+// with fs_r / ls_r the run's end slots and Ks / Ke the profile sums on them (earlier runs' and
+// its own).  Which earlier runs hold a slot, and the G sums, do not depend on the pedestals:
+// run_links_kernel finds them in parallel (bit masks over the previous 128 runs).  What is left
+// is a triangular system in the P's -- every P_r is a fixed function of earlier ones -- and a
+// triangular system has exactly one solution, which plain iteration P <- F(P) reaches from any
+// start after as many sweeps as its longest chain of dependences that MATTER: a run whose last
+// slot is the smaller end takes its pedestal from there, and a last slot is fresh -- only the
+// run's own window, and the neighbour's where pressure shifts make two windows alternate, has
+// added to it -- so such a run does not look at history at all.  On every line table tried
+// (uniform, banded, sparse: profiles/r04_pedestal_branches.txt) that is all but a handful of
+// runs, and chains are 2-4 runs long.  run_relax_kernel: one wavefront per 64 consecutive runs
+// (lane = run), sweeps inside the chunk until nothing changes, earlier chunks' values taken from
+// the previous launch.  Three launches; the second and third report whether anything changed,
+// and a launch that changed nothing has verified a fixed point, i.e. the solution the serial
+// chain would compute with the same formula, bit for bit and independent of how it was reached.
+// Levels that have not settled by then (or whose windows reach back more than 128 runs) keep
+// run_chain_kernel.  ~25 us for the 400 k-line benchmark table, where the serial forms take a
+// wavefront 0.2-0.75 ms: one wavefront issues an instruction every fourth cycle at best, and
+// 5 300 dependent steps of ~100 instructions are 2 M cycles however they are arranged.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double read_lane(double value, int lane)
 {
@@ -338,256 +382,233 @@ __device__ __forceinline__ double read_lane(double value, int lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-constexpr int kLinkReach = 64;      // history visible to a run: the previous 64 runs
+constexpr int kLinkReach = 128;     // history visible to a run: the previous 128 runs
 
-// prefix_last[r] = max over q <= r of the runs' last slots (one workgroup per level).
+// Per level: [0] 1 while the parallel chain applies (cleared by run_links_kernel where a window
+// reaches back beyond kLinkReach runs), [1] / [2] something changed in the second / third
+// relaxation launch, [3] spare.
+constexpr int kChainState = 4;
+
+__device__ __forceinline__ bool chain_settled(const int * state)
+{
+    return state[0] != 0 && (state[1] == 0 || state[2] == 0);
+}
+
+// prefix_last[r] = max over q <= r of the runs' last slots (one workgroup per level: every thread
+// takes a contiguous share of the runs, the shares' maxima are scanned, the shares written back).
+// Also resets the level's chain state.
 __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __restrict__ run_count,
                                                           int max_runs,
                                                           const RunMeta * __restrict__ runs,
-                                                          int * __restrict__ prefix_last)
+                                                          int * __restrict__ prefix_last,
+                                                          int * __restrict__ state, int start_state)
 {
-    __shared__ int wave_max[16];
-    __shared__ int carry;
+    __shared__ int wave_max[kScanThreads/64];
     const int level = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int count = run_count[level];
     const RunMeta * meta = runs + (long long)level*max_runs;
     int * out = prefix_last + (long long)level*max_runs;
-    if (threadIdx.x == 0) carry = -1;
-    __syncthreads();
-    for (int base = 0; base < count; base += kScanThreads)
+    if (threadIdx.x < kChainState)
     {
-        const int r = base + threadIdx.x;
-        int value = r < count ? meta[r].last_slot : -1;
-        for (int offset = 1; offset < 64; offset <<= 1)
-        {
-            const int up = __shfl_up(value, offset, 64);
-            if (lane >= offset) value = max(value, up);
-        }
-        if (lane == 63) wave_max[wave] = value;
-        __syncthreads();
-        int before = carry;
-        for (int i = 0; i < wave; ++i) before = max(before, wave_max[i]);
-        value = max(value, before);
-        if (r < count) out[r] = value;
-        __syncthreads();
-        if (threadIdx.x == kScanThreads - 1) carry = value;
-        __syncthreads();
+        state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state : 0;
+    }
+    const int share = (count + kScanThreads - 1)/kScanThreads;
+    const int begin = min(threadIdx.x*share, count), end = min(begin + share, count);
+    int mine = -1;
+    for (int r = begin; r < end; ++r) mine = max(mine, meta[r].last_slot);
+    int scan = mine;
+    for (int offset = 1; offset < 64; offset <<= 1)
+    {
+        const int up = __shfl_up(scan, offset, 64);
+        if (lane >= offset) scan = max(scan, up);
+    }
+    if (lane == 63) wave_max[wave] = scan;
+    __syncthreads();
+    int before = -1;
+    for (int i = 0; i < wave; ++i) before = max(before, wave_max[i]);
+    const int up = __shfl_up(scan, 1, 64);
+    int running = max(before, lane > 0 ? up : -1);      // everything before this thread's share
+    for (int r = begin; r < end; ++r)
+    {
+        running = max(running, meta[r].last_slot);
+        out[r] = running;
     }
 }
 
-__global__ __launch_bounds__(256) void run_links_kernel(const int * __restrict__ run_count,
-                                                        int max_runs, int slot_stride,
-                                                        const RunMeta * __restrict__ runs,
-                                                        const double * __restrict__ slot_sums,
-                                                        const int * __restrict__ prefix_last,
-                                                        RunLink * __restrict__ links,
-                                                        int * __restrict__ regular)
+// One wavefront per run: lane j looks at run r-1-j and r-65-j -- does it hold this run's end
+// slots, and what did it add there -- and at runs r+1+j, r+65+j for the next run of the same
+// bin (the bins' totals are summed along those links, in row order).
+__global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ run_count,
+                                                       int max_runs, int slot_stride,
+                                                       const RunMeta * __restrict__ runs,
+                                                       const double * __restrict__ slot_sums,
+                                                       const int * __restrict__ prefix_last,
+                                                       RunLink * __restrict__ links,
+                                                       int * __restrict__ state)
 {
     const int level = blockIdx.y;
-    const int r = blockIdx.x*blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
     const int count = run_count[level];
-    if (r >= count) return;
     const RunMeta * meta = runs + (long long)level*max_runs;
     const double * sums = slot_sums + (long long)level*max_runs*slot_stride;
-    const RunMeta m = meta[r];
-    // Nothing older than the visible history may hold one of this run's end slots.
-    if (r > kLinkReach &&
-        prefix_last[(long long)level*max_runs + r - kLinkReach - 1] >= m.first_slot)
+    for (int r = blockIdx.x; r < count; r += gridDim.x)
     {
-        atomicAnd(&regular[level], 0);
-    }
-    double gs = 0., ge = 0.;
-    unsigned long long mask_s = 0, mask_e = 0;
-    for (int j = 0; j < kLinkReach && r - 1 - j >= 0; ++j)
-    {
-        const int q = r - 1 - j;
-        const RunMeta e = meta[q];
-        if (e.first_slot <= m.first_slot && m.first_slot <= e.last_slot)
+        const RunMeta m = meta[r];
+        // Nothing older than the visible history may hold one of this run's end slots.
+        if (lane == 0 && r > kLinkReach &&
+            prefix_last[(long long)level*max_runs + r - kLinkReach - 1] >= m.first_slot)
         {
-            mask_s |= 1ull << j;
-            gs += sums[(long long)q*slot_stride + (m.first_slot - e.first_slot)];
+            atomicAnd(&state[level*kChainState], 0);
         }
-        if (e.first_slot <= m.last_slot && m.last_slot <= e.last_slot)
+        RunLink link;
+        double gs = 0., ge = 0.;
+        bool seen_before = false;
+        for (int half = 0; half < 2; ++half)
         {
-            mask_e |= 1ull << j;
-            ge += sums[(long long)q*slot_stride + (m.last_slot - e.first_slot)];
+            const int q = r - 1 - half*64 - lane;
+            bool holds_s = false, holds_e = false;
+            double at_s = 0., at_e = 0.;
+            if (q >= 0)
+            {
+                const RunMeta e = meta[q];
+                holds_s = e.first_slot <= m.first_slot && m.first_slot <= e.last_slot;
+                holds_e = e.first_slot <= m.last_slot && m.last_slot <= e.last_slot;
+                if (holds_s) at_s = sums[(long long)q*slot_stride + (m.first_slot - e.first_slot)];
+                if (holds_e) at_e = sums[(long long)q*slot_stride + (m.last_slot - e.first_slot)];
+                seen_before = seen_before || e.bin == m.bin;
+            }
+            link.mask_s[half] = __ballot(holds_s);
+            link.mask_e[half] = __ballot(holds_e);
+            gs += at_s;
+            ge += at_e;
+        }
+        for (int offset = 32; offset > 0; offset >>= 1)
+        {
+            gs += __shfl_xor(gs, offset, 64);
+            ge += __shfl_xor(ge, offset, 64);
+        }
+        int next = -1;
+        for (int half = 0; half < 2 && next < 0; ++half)
+        {
+            const int q = r + 1 + half*64 + lane;
+            const unsigned long long same = __ballot(q < count && meta[min(q, count - 1)].bin == m.bin);
+            if (same != 0ull) next = r + 1 + half*64 + __builtin_ctzll(same);
+        }
+        const bool first_of_bin = __ballot(seen_before) == 0ull;
+        if (lane == 0)
+        {
+            link.ks = gs + m.vs;
+            link.ke = ge + m.ve;
+            link.bin = m.bin;
+            link.next_same = next;
+            link.n_slots = m.n_slots;
+            link.first_of_bin = first_of_bin ? 1 : 0;
+            links[(long long)level*max_runs + r] = link;
         }
     }
-    RunLink link;
-    link.ks = gs + m.vs;
-    link.ke = ge + m.ve;
-    link.mask_s = mask_s;
-    link.mask_e = mask_e;
-    link.bin = m.bin;
-    link.pad0 = 0;
-    link.pad1 = 0;
-    links[(long long)level*max_runs + r] = link;
 }
 
-__device__ __forceinline__ double shuffle_up(double value, int offset)
+// min(k_s, k_e), taken like the serial chain takes it (run_chain_kernel).
+__device__ __forceinline__ double run_pedestal(double k_s, double k_e, int n_slots)
 {
-    return __shfl_up(value, offset, 64);
+    return (n_slots == 1 || !(k_s - k_e > 0.)) ? k_s : k_e;
 }
 
-// Inclusive scan over the 64 lanes of the composition of L -> min(L + a, c): the element (a, c)
-// of a lane becomes (sum of the a's up to it, the smallest c_i + (a's after i)).
-__device__ __forceinline__ void wave_min_plus_scan(double & a, double & c)
+// One wavefront per 64 consecutive runs (lane = run).  Inside the chunk the system is solved
+// exactly, run by run (forward substitution: run t's value is broadcast, the later lanes whose
+// masks name it add it to their sums -- ~20 instructions a step); what earlier chunks hold comes
+// from the previous launch (step 0: zero).  So launch k is exact for every chain of dependences
+// that crosses at most k chunk boundaries, whatever its length inside a chunk (the runs of the
+// 2 cut_off + 2 windows clipped at either end of the grid form such chains: each holds the end
+// slot of all the others).  Steps 1 and 2 report a change and sum the bins' totals from the
+// values they were handed -- final if the launch changes nothing anywhere.
+__global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ run_count,
+                                                       int max_runs, int n_bins, int step,
+                                                       const RunLink * __restrict__ links,
+                                                       const double * __restrict__ p_in,
+                                                       double * __restrict__ p_out,
+                                                       int * __restrict__ state,
+                                                       double * __restrict__ bin_sum)
 {
-    const double inf = __builtin_inf();
-#define LBL_MIN_PLUS_STEP(CONTROL, ROWS)                                   \
-    {                                                                       \
-        const double a_left = dpp_from<CONTROL, ROWS>(0., a);               \
-        const double c_left = dpp_from<CONTROL, ROWS>(inf, c);              \
-        c = fmin(c_left + a, c);                                            \
-        a = a_left + a;                                                     \
-    }
-    LBL_MIN_PLUS_STEP(kRowShr1, 0xf)
-    LBL_MIN_PLUS_STEP(kRowShr2, 0xf)
-    LBL_MIN_PLUS_STEP(kRowShr4, 0xf)
-    LBL_MIN_PLUS_STEP(kRowShr8, 0xf)
-    LBL_MIN_PLUS_STEP(kRowBcast15, 0xa)
-    LBL_MIN_PLUS_STEP(kRowBcast31, 0xc)
-#undef LBL_MIN_PLUS_STEP
-}
-
-// Runs per (min,+) scan.  A block ends where a run's first slot is no longer held by every run
-// before it in the block (after 2*cut_off + 1 = 51 runs of one-run-per-cell tables) or where its
-// last slot is held by some but not all of them -- which is what lines within a pressure shift of
-// an integer wavenumber do: they alternate between two windows, and each alternation ends a block.
-// The benchmark tables (shifts up to 0.01 cm-1 at 1 atm) take ~1 700 steps for their 4 999 cells, so
-// the wider scan buys little there (0.52 -> 0.48 ms); tables without shifts take a tenth of that.
-constexpr int kScanBlock = 64;
-// (The chain kernels are single workgroups that start beside a resident accumulate grid, whose
-// workgroups hold 12-27 KB of LDS each, six or seven to a CU: what a chain kernel asks for must
-// fit in what they leave, ~50 KB, or it waits for a CU to drain -- 1.4 ms in a kernel trace when
-// the fallback below asked for 108 KB only to find nothing to do.)
-constexpr int kLinkChunk = 128;     // run links staged in LDS at a time
-
-// One wavefront per level; only acts on levels run_links_kernel left flagged regular.
-__global__ __launch_bounds__(64) void run_chain_scan_kernel(const int * __restrict__ run_count,
-                                                            int max_runs, int n_bins,
-                                                            const RunLink * __restrict__ links,
-                                                            const int * __restrict__ regular,
-                                                            double * __restrict__ bin_sum)
-{
-    extern __shared__ double lds[];
-    const int level = blockIdx.x;
+    __shared__ double history[kLinkReach];      // P of runs base-128 ... base-1 (previous launch)
+    const int level = blockIdx.y;
     const int lane = threadIdx.x;
-    if (!regular[level]) return;
-    // The chain is the critical path of the pedestal pass and shares its SIMD with
-    // accumulate wavefronts: let the arbiter prefer it.
-    __builtin_amdgcn_s_setprio(3);
-    double * bins = lds;                                    // [n_bins]
-    double * history = bins + n_bins;                       // pedestals of the last 128 runs
-    RunLink * staged = reinterpret_cast<RunLink *>(history + 128);   // [kLinkChunk]
-    for (int s = lane; s < n_bins; s += 64) bins[s] = 0.;
-    for (int s = lane; s < 128; s += 64) history[s] = 0.;
     const int count = run_count[level];
+    const int base = blockIdx.x*64;
+    int * flags = state + level*kChainState;
+    if (base >= count || flags[0] == 0) return;
+    if (step == 2 && flags[1] == 0) return;         // the second launch verified the first
     const RunLink * link = links + (long long)level*max_runs;
-    const double inf = __builtin_inf();
-    int staged_from = 0, staged_to = 0;
-    __syncthreads();
-    int b = 0;
-    while (b < count)
+    const double * from = p_in + (long long)level*max_runs;
+    const int r = base + lane;
+    const bool valid = r < count;
+    RunLink mine;
+    mine.ks = mine.ke = 0.;
+    mine.mask_s[0] = mine.mask_s[1] = mine.mask_e[0] = mine.mask_e[1] = 0ull;
+    mine.bin = -1; mine.next_same = -1; mine.n_slots = 0; mine.first_of_bin = 0;
+    if (valid) mine = link[r];
+    const unsigned long long mask_s0 = mine.mask_s[0], mask_s1 = mine.mask_s[1];
+    const unsigned long long mask_e0 = mine.mask_e[0], mask_e1 = mine.mask_e[1];
+    double given = 0.;
+    // Sums over the runs of earlier chunks: bit j of a mask is run r-1-j, history entry t is run
+    // base-128+t, so entry t is bit lane+127-t.  Oldest first; entries no lane names are skipped.
+    double before_s = 0., before_e = 0.;
+    if (step > 0 && base > 0)
     {
-        if (b + kScanBlock > staged_to && staged_to < count)
+        history[lane] = base - 128 + lane >= 0 ? from[base - 128 + lane] : 0.;
+        history[64 + lane] = base - 64 + lane >= 0 ? from[base - 64 + lane] : 0.;
+        __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
+        const unsigned long long any1 = mask_s1 | mask_e1, any0 = mask_s0 | mask_e0;
+        const int top_bit = any1 ? 127 - __builtin_clzll(any1) : any0 ? 63 - __builtin_clzll(any0) : -1;
+        int oldest = top_bit >= lane ? lane + 127 - top_bit : 128;
+        for (int offset = 32; offset > 0; offset >>= 1)
         {
-            // Stage the next chunk of links (coalesced) so that the serial part reads LDS.
-            staged_from = b;
-            staged_to = min(count, b + kLinkChunk);
-            for (int i = lane; i < staged_to - staged_from; i += 64)
-            {
-                staged[i] = link[staged_from + i];
-            }
-            __builtin_amdgcn_wave_barrier();   // one wavefront: LDS keeps its order
+            oldest = min(oldest, __shfl_xor(oldest, offset, 64));
         }
-        const int r = b + lane;
-        const bool candidate = r < staged_to;
-        RunLink mine;
-        mine.ks = mine.ke = 0.;
-        mine.mask_s = mine.mask_e = 0;
-        mine.bin = -1;
-        if (candidate) mine = staged[r - staged_from];
-        // In-block part of the masks: bit j < lane is run r-1-j >= b.
-        const unsigned long long in_block = lane == 0 ? 0ull : ((1ull << lane) - 1ull);
-        const bool first_held = (mine.mask_s & in_block) == in_block;
-        const bool last_free = (mine.mask_e & in_block) == 0ull;
-        const bool last_held = (mine.mask_e & in_block) == in_block;
-        const bool fits = candidate && first_held && (last_free || last_held);
-        const unsigned long long fit_mask = __ballot(fits);
-        const int size = __builtin_ctzll(~fit_mask);        // leading run of ones (>= 1)
-        const bool active = lane < size;
-
-        // Pedestals of covering runs before the block.  History entry t is run b-1-t, which
-        // is bit t + lane of this lane's masks; lane t keeps entry t in a register.
-        const unsigned long long old_s = active ? mine.mask_s >> lane : 0ull;
-        const unsigned long long old_e = active ? mine.mask_e >> lane : 0ull;
-        const double entry = b - 1 - lane >= 0 ? history[(b - 1 - lane) & 127] : 0.;
-        double prev_s = 0., prev_e = 0.;
-        // Usual case: the covering runs are the most recent J ones (masks 0..01..1), so the
-        // sums are prefix sums of the history.
-        const bool contiguous = ((old_s & (old_s + 1ull)) | (old_e & (old_e + 1ull))) == 0ull;
-        if (__ballot(!contiguous) == 0ull)
+        for (int t = max(oldest, 0); t < 128; ++t)
         {
-            const double prefix = wave_prefix_sum(entry);
-            const int count_s = __builtin_popcountll(old_s), count_e = __builtin_popcountll(old_e);
-            const double at_s = __shfl(prefix, (count_s - 1) & 63, 64);
-            const double at_e = __shfl(prefix, (count_e - 1) & 63, 64);
-            prev_s = count_s ? at_s : 0.;
-            prev_e = count_e ? at_e : 0.;
+            const double value = history[t];
+            const int j = lane + 127 - t;           // 64 <= j for the lanes that can name it
+            const bool far = j >= 64;
+            const unsigned long long word_s = far ? mask_s1 : mask_s0;
+            const unsigned long long word_e = far ? mask_e1 : mask_e0;
+            const int shift = j & 63;
+            if (j < 128 && ((word_s >> shift) & 1ull)) before_s += value;
+            if (j < 128 && ((word_e >> shift) & 1ull)) before_e += value;
         }
-        else
-        {
-            // Arbitrary masks: walk the history up to the farthest entry any lane needs.
-            const unsigned long long both = old_s | old_e;
-            int reach = both ? 64 - __builtin_clzll(both) : 0;
-            for (int offset = 32; offset > 0; offset >>= 1)
-            {
-                reach = max(reach, __shfl_xor(reach, offset, 64));
-            }
-            for (int t = 0; t < reach; ++t)
-            {
-                const double p = read_lane(entry, t);
-                if ((old_s >> t) & 1ull) prev_s += p;
-                if ((old_e >> t) & 1ull) prev_e += p;
-            }
-        }
-
-        // Element of the (min,+) scan: L_r = min(L_{r-1} + a, c).
-        double a = 0., c = inf;      // identity (right of the block)
-        if (active)
-        {
-            const double k_s = mine.ks - prev_s;
-            const double k_e = mine.ke - prev_e;
-            if (last_held && lane > 0)
-            {
-                a = inf;
-                c = fmin(k_s, k_e);
-            }
-            else
-            {
-                a = k_e;
-                c = k_s;
-            }
-        }
-        const double a_own = a, c_own = c;
-        static_assert(kScanBlock == 64, "wave_min_plus_scan covers the wavefront");
-        wave_min_plus_scan(a, c);
-        const double total = fmin(a, c);                    // L_r with L_{b-1} = 0
-        const double before = dpp_from<kWaveShr1, 0xf>(0., total);     // lane 0 keeps 0
-        // P_r = L_r - L_{r-1}; on the branch L_r = L_{r-1} + a it is a itself, exactly.
-        const double pedestal = (before + a_own <= c_own) ? a_own : c_own - before;
-        if (active)
-        {
-            history[r & 127] = pedestal;
-            if (mine.bin >= 0 && mine.bin < n_bins) atomicAdd(&bins[mine.bin], pedestal);
-        }
-        __builtin_amdgcn_wave_barrier();
-        b += size;
     }
-    __syncthreads();
-    for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = bins[s];
+    if (step > 0 && valid) given = from[r];
+    // The chunk itself: run t of the chunk is bit lane-1-t of the later lanes' first words.
+    double p = 0.;
+    const int last = min(64, count - base);
+    for (int t = 0; t < last; ++t)
+    {
+        const double candidate = run_pedestal(mine.ks - before_s, mine.ke - before_e, mine.n_slots);
+        const double settled = read_lane(candidate, t);
+        if (lane == t) p = candidate;
+        const int j = lane - 1 - t;
+        if (j >= 0)
+        {
+            if ((mask_s0 >> j) & 1ull) before_s += settled;
+            if ((mask_e0 >> j) & 1ull) before_e += settled;
+        }
+    }
+    if (valid) p_out[(long long)level*max_runs + r] = p;
+    if (step > 0)
+    {
+        const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
+        if (__ballot(moved) != 0ull && lane == 0)
+        {
+            atomicOr(&flags[step], 1);      // (run_prefix_kernel cleared the flags)
+        }
+        if (valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins)
+        {
+            double total = 0.;
+            for (int q = r; q >= 0; q = link[q].next_same) total += from[q];
+            bin_sum[(long long)level*n_bins + mine.bin] = total;
+        }
+    }
 }
 
 constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at a time
@@ -602,14 +623,14 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
                                                        GridSpec g, int n_cells, int n_bins,
                                                        const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
-                                                       const int * __restrict__ regular,
+                                                       const int * __restrict__ state,
                                                        double * __restrict__ global_slots,
                                                        double * __restrict__ bin_sum)
 {
     extern __shared__ double lds[];
     const int level = blockIdx.x;
     const int lane = threadIdx.x;
-    if (regular != nullptr && regular[level]) return;    // run_chain_scan_kernel took it
+    if (state != nullptr && chain_settled(state + level*kChainState)) return;   // relaxation did it
     __builtin_amdgcn_s_setprio(3);
     // LDS carve: [2 x staged slot sums][slots][bin sums]; without LDS room the last two are in HBM.
     double * staged = lds;
@@ -835,12 +856,6 @@ __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __re
 
 // The pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are already in
 // HBM, in two halves (pedestal_find_runs, pedestal_finish) on the same stream.
-__global__ void fill_int_kernel(int * data, int n, int value)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if (i < n) data[i] = value;
-}
-
 inline void pedestal_check(hipError_t status, const char * what)
 {
     if (status != hipSuccess)
@@ -875,10 +890,12 @@ inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const
 }
 
 // Second half: waits for the run counts, then sums, links, chain and tables on `stream`;
-// leaves cell_sum / point_sum for pedestal_apply_kernel.
+// leaves cell_sum / point_sum for pedestal_apply_kernel.  parallel_chain: the relaxation
+// (run_relax_kernel) with the serial chain behind it for the levels it leaves; else the serial
+// chain alone.
 inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                             const LineWing * wing, const LineCore * core, const GridSpec & g,
-                            int count, int n_cells, bool scan_chain = true)
+                            int count, int n_cells, bool parallel_chain = true)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
@@ -887,6 +904,13 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     ws.bin_sum.reserve((size_t)count*n_bins);
     ws.cell_sum.reserve((size_t)count*n_cells);
     ws.point_sum.reserve((size_t)count*n_cells);
+    ws.state.reserve((size_t)count*kChainState);
+    if (parallel_chain)
+    {
+        // Bins without a run keep this zero (the relaxation only writes the bins it has runs for).
+        check(hipMemsetAsync(ws.bin_sum.data, 0, (size_t)count*n_bins*sizeof(double), stream),
+              "bin sums");
+    }
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
     for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
@@ -897,43 +921,36 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
                        ws.run_start.data, ws.run_count.data, max_runs, slot_stride,
                        ws.runs.data, ws.slot_sums.data);
     check(hipGetLastError(), "run_sums_kernel");
-    // Fast chain where the windows are monotone (flag per level), serial chain otherwise.
-    ws.links.reserve((size_t)count*max_runs);
-    ws.regular.reserve((size_t)count);
-    const bool try_scan = scan_chain && n_bins*sizeof(double) + 128*sizeof(double) +
-                          kLinkChunk*sizeof(RunLink) <= 150*1024;
-    check(hipMemsetAsync(ws.regular.data, 0, count*sizeof(int), stream), "regular flags");
-    if (try_scan)
+    ws.prefix_last.reserve((size_t)count*max_runs);
+    hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
+                       ws.run_count.data, max_runs, ws.runs.data, ws.prefix_last.data,
+                       ws.state.data, parallel_chain ? 1 : 0);
+    if (parallel_chain)
     {
-        hipLaunchKernelGGL(fill_int_kernel, dim3((count + 255)/256), dim3(256), 0, stream,
-                           ws.regular.data, count, 1);
-        ws.prefix_last.reserve((size_t)count*max_runs);
-        hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
-                           ws.run_count.data, max_runs, ws.runs.data, ws.prefix_last.data);
-        hipLaunchKernelGGL(run_links_kernel, dim3((max_runs + 255)/256, count), dim3(256), 0,
+        ws.links.reserve((size_t)count*max_runs);
+        ws.pedestals[0].reserve((size_t)count*max_runs);
+        ws.pedestals[1].reserve((size_t)count*max_runs);
+        hipLaunchKernelGGL(run_links_kernel, dim3(std::min(max_runs, 65535), count), dim3(64), 0,
                            stream, ws.run_count.data, max_runs, slot_stride, ws.runs.data,
-                           ws.slot_sums.data, ws.prefix_last.data, ws.links.data,
-                           ws.regular.data);
-        const size_t scan_lds = (size_t)(n_bins + 128)*sizeof(double) + kLinkChunk*sizeof(RunLink);
-        if (scan_lds > 64*1024)
+                           ws.slot_sums.data, ws.prefix_last.data, ws.links.data, ws.state.data);
+        const dim3 chunks((max_runs + 63)/64, count);
+        for (int step = 0; step < 3; ++step)
         {
-            check(hipFuncSetAttribute(reinterpret_cast<const void *>(run_chain_scan_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)scan_lds), "LDS opt-in");
+            hipLaunchKernelGGL(run_relax_kernel, chunks, dim3(64), 0, stream, ws.run_count.data,
+                               max_runs, n_bins, step, ws.links.data,
+                               ws.pedestals[(step + 1) & 1].data, ws.pedestals[step & 1].data,
+                               ws.state.data, ws.bin_sum.data);
         }
-        hipLaunchKernelGGL(run_chain_scan_kernel, dim3(count), dim3(64), scan_lds, stream,
-                           ws.run_count.data, max_runs, n_bins, ws.links.data, ws.regular.data,
-                           ws.bin_sum.data);
-        check(hipGetLastError(), "run_chain_scan_kernel");
+        check(hipGetLastError(), "run_relax_kernel");
     }
-    // The serial chain takes the levels the scan left (flag `regular` cleared; with an ascending
-    // table: none, or the few whose windows are crowded with more runs than the scan's masks
-    // reach).  Behind a scan it is launched in its small-LDS form (slots of the spectrum in HBM,
-    // the active ones in registers): it usually only looks at the flags and returns, and must
-    // not queue for most of a CU's LDS to do that.
+    // The serial chain takes the levels the relaxation left (windows that reach back more than
+    // kLinkReach runs: rows far out of order; or not settled after three launches).  Behind the
+    // relaxation it is launched in its small-LDS form (slots of the spectrum in HBM, the active
+    // ones in registers): it usually only looks at the flags and returns, and must not queue for
+    // most of a CU's LDS to do that (the accumulate workgroups beside it hold 12-27 KB each).
     const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
     const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
-    if (lds_bytes <= 160*1024 - 512 && !try_scan)
+    if (lds_bytes <= 160*1024 - 512 && !parallel_chain)
     {
         if (lds_bytes > 64*1024)
         {
@@ -948,7 +965,7 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         auto chain = slot_stride <= 64 ? run_chain_kernel<true, true> : run_chain_kernel<true, false>;
         hipLaunchKernelGGL(chain, dim3(count), dim3(64), lds_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, ws.regular.data, (double *)nullptr,
+                           ws.runs.data, ws.slot_sums.data, ws.state.data, (double *)nullptr,
                            ws.bin_sum.data);
     }
     else
@@ -957,7 +974,7 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         auto chain = slot_stride <= 64 ? run_chain_kernel<false, true> : run_chain_kernel<false, false>;
         hipLaunchKernelGGL(chain, dim3(count), dim3(64), staged_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, ws.regular.data, ws.slots.data,
+                           ws.runs.data, ws.slot_sums.data, ws.state.data, ws.slots.data,
                            ws.bin_sum.data);
     }
     check(hipGetLastError(), "run_chain_kernel");

@@ -377,10 +377,12 @@ def test_farfield_series_option(engine, oracle, remove_pedestal):
 
 
 def test_pedestal_chain_variants_agree(engine, oracle):
-    """The pedestal recurrence has two implementations (pedestal.h): the serial chain and the
-    (min,+) scan over blocks of windows.  Both must meet the bar against the oracle and agree
-    with each other far below it -- on an ascending table with many lines sitting next to
-    integer wavenumbers (pressure shifts make windows step backwards there) and many levels."""
+    """The pedestal recurrence has two implementations (pedestal.h): the relaxation (what runs
+    by default) and the serial chain behind it.  Both must meet the bar against the oracle and
+    agree with each other far below it -- on an ascending table with many lines sitting next to
+    integer wavenumbers (pressure shifts make windows step backwards there) and many levels, on
+    grids whose windows are clipped at both ends, with one point per wavenumber (the last grid
+    point is an integer), narrow and wide cut-offs."""
     from pylbl_amd import synthetic
     table = synthetic.line_table("CO2", 2290., 2400., num_lines=8000, seed=95,
                                  tips_range=(150, 400))
@@ -390,25 +392,37 @@ def test_pedestal_chain_variants_agree(engine, oracle):
     order = np.argsort(table.nu, kind="stable")
     table = table.subset(order)
     atmos = synthetic.standard_atmosphere(6)
-    v0, vn, npv = 2300, 2380, 100
     molecule = engine.load(table)
-    results = {}
-    for scan in (1, 0):
-        engine.set_option("scan_chain", scan)
-        results[scan] = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
-                                       remove_pedestal=True)
-    engine.set_option("scan_chain", 1)
-    plain = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv)
-    # (the serial form is the less accurate of the two at low pressure: ~2e-9 vs ~1e-10)
-    assert np.max(np.abs(results[1] - results[0])/plain) < 1.e-7
-    case = golden_io.Case("chain", 0, 0, 0, 0, v0, vn, npv, 25, True, None, 0)
-    for level in (0, 5):
-        k_ref, _ = oracle.absorption_port(table, atmos.t[level], atmos.p[level],
-                                          atmos.vmr["CO2"][level], v0, vn, npv,
-                                          remove_pedestal=True)
-        for scan in (1, 0):
-            assert_spectrum(results[scan][level], k_ref, case, f"scan={scan} level {level}",
-                            plain[level])
+    variants = {"relaxation": 1, "serial": 0}
+    try:
+        # (first rows within cut_off + 1 of v0 everywhere: the reference's range rule would stop
+        # at row 0 otherwise, absorption.c:80-83)
+        for v0, vn, npv, cut in ((2300, 2380, 100, 25), (2270, 2420, 10, 25), (2312, 2340, 7, 25),
+                                 (2300, 2380, 1, 25), (2292, 2340, 20, 3), (2300, 2380, 4, 30),
+                                 (2300, 2380, 4, 40)):
+            results = {}
+            for name, scan in variants.items():
+                engine.set_option("scan_chain", scan)
+                results[name] = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0,
+                                               vn, npv, cut_off=cut, remove_pedestal=True)
+            engine.set_option("scan_chain", 1)
+            plain = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv,
+                                   cut_off=cut)
+            # (the serial form is the less accurate of the two at low pressure: ~2e-9 vs ~1e-10)
+            scale = np.maximum(plain, 1e-300)
+            assert np.max(np.abs(results["relaxation"] - results["serial"])/scale) < 1.e-7, \
+                (v0, vn, npv, cut)
+            case = golden_io.Case("chain", 0, 0, 0, 0, v0, vn, npv, cut, True, None, 0)
+            for level in (0, 5):
+                k_ref, _ = oracle.absorption_port(table, atmos.t[level], atmos.p[level],
+                                                  atmos.vmr["CO2"][level], v0, vn, npv,
+                                                  cut_off=cut, remove_pedestal=True)
+                for name in variants:
+                    assert_spectrum(results[name][level], k_ref, case,
+                                    f"{name} level {level} grid {(v0, vn, npv, cut)}",
+                                    plain[level])
+    finally:
+        engine.set_option("scan_chain", 1)
     engine.free(molecule)
 
 
