@@ -230,12 +230,19 @@ __device__ __forceinline__ int slot_point(int slot, int n_cells, int n_per_v, in
 // LineCore: three dependent loads, side by side for 64 rows) into LDS, then every lane walks the
 // staged rows in the reference's row order.  (Walking the rows straight from HBM put those three
 // round trips on every row: 80-130 us for the benchmark's tables, most of it waiting.)
+// A slot inside a row's core range takes the region chain (wells_profile: a few hundred
+// instructions against a dozen for the far wing).  Slots are whole wavenumbers, so that is one
+// lane in every third row or so -- and the wavefront paid the chain for each such row.  Those
+// (row, lane) pairs are set aside and evaluated together, one pair per lane, once per batch of
+// rows; every lane then adds its own in row order.
 struct StagedRow
 {
     double centre, g2, bl;
     double repwid, y, amp;
     int first, last, core_first, core_last;
 };
+
+constexpr int kCorePairs = 256;     // (row, lane) pairs set aside before they are evaluated
 
 __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restrict__ wing,
                                                       const LineCore * __restrict__ core,
@@ -248,6 +255,8 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                                                       double * __restrict__ slot_sums)
 {
     __shared__ StagedRow staged[64];
+    __shared__ unsigned short pair_of[kCorePairs];      // row << 6 | lane
+    __shared__ double pair_value[kCorePairs];
     const int level = blockIdx.y;
     const int lane = threadIdx.x;
     const int count = run_count[level];
@@ -270,14 +279,18 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
         for (int pass = 0; pass < passes; ++pass)
         {
             const int q0 = pass*64;
-            const int q = q0 + lane;
-            const bool active = q < n_slots;
-            const int slot = (extra && q == n_slots - 1) ? n_cells : first_slot + q;
-            const int point = slot_point(active ? slot : first_slot, n_cells, g.n_per_v, g.n);
-            const double step = (double)point*g.dv;        // absorption.c:39
-            const double v = (double)g.v0 + step;
-            const bool holds_first = (q0 == 0);
-            const bool holds_last = (q0 + 64 >= n_slots);
+            auto point_of = [&](int in_pass) {
+                const int q = q0 + in_pass;
+                const int slot = (extra && q == n_slots - 1) ? n_cells : first_slot + q;
+                return slot_point(q < n_slots ? slot : first_slot, n_cells, g.n_per_v, g.n);
+            };
+            auto wavenumber_of = [&](int point) {
+                const double step = (double)point*g.dv;        // absorption.c:39
+                return (double)g.v0 + step;
+            };
+            const bool active = q0 + lane < n_slots;
+            const int point = point_of(lane);
+            const double v = wavenumber_of(point);
             double total = 0.;
             bool open = true;
             for (int base = row_begin; base < row_end && open; base += 64)
@@ -297,6 +310,28 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                     staged[lane] = row;
                 }
                 __builtin_amdgcn_wave_barrier();    // one wavefront: LDS keeps program order
+                int n_pairs = 0;
+                // The pairs set aside so far: the region chain for 64 of them at a time, then
+                // every lane adds its own (in the order they were set aside: row order).
+                auto settle_pairs = [&]() {
+                    for (int e0 = 0; e0 < n_pairs; e0 += 64)
+                    {
+                        if (e0 + lane < n_pairs)
+                        {
+                            const int pair = pair_of[e0 + lane];
+                            const StagedRow l = staged[pair >> 6];
+                            const double d = wavenumber_of(point_of(pair & 63)) - l.centre;
+                            pair_value[e0 + lane] = l.amp*wells_profile(d*l.repwid, l.y);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int e = 0; e < n_pairs; ++e)
+                    {
+                        if ((pair_of[e] & 63) == lane) total += pair_value[e];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    n_pairs = 0;
+                };
                 for (int r = 0; r < rows; ++r)
                 {
                     const StagedRow l = staged[r];
@@ -305,29 +340,33 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                         open = false;
                         break;      // an empty or different window ends the run
                     }
+                    const bool in_core = active && point >= l.core_first && point <= l.core_last;
                     const double d = v - l.centre;
-                    double value;
-                    if (point < l.core_first || point > l.core_last)
+                    const double far_wing = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                    total += in_core ? 0. : far_wing;
+                    const unsigned long long cores = __ballot(in_core);
+                    if (cores != 0ull)
                     {
-                        value = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
-                    }
-                    else
-                    {
-                        value = l.amp*wells_profile(d*l.repwid, l.y);
-                    }
-                    total += value;
-                    if (holds_first)
-                    {
-                        const double at_first = __shfl(value, 0, 64);
-                        vs += at_first;
-                    }
-                    if (holds_last)
-                    {
-                        ve += __shfl(value, n_slots - 1 - q0, 64);
+                        if (in_core)
+                        {
+                            const int at = n_pairs + __builtin_popcountll(cores & ((1ull << lane) - 1ull));
+                            pair_of[at] = (unsigned short)(r << 6 | lane);
+                        }
+                        n_pairs += __builtin_popcountll(cores);
+                        if (n_pairs > kCorePairs - 64)
+                        {
+                            __builtin_amdgcn_wave_barrier();
+                            settle_pairs();
+                        }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (n_pairs > 0) settle_pairs();
             }
-            if (active) sums[q] = total;
+            if (active) sums[q0 + lane] = total;
+            // The run's own values on its end slots are those lanes' totals.
+            if (q0 == 0) vs = __shfl(total, 0, 64);
+            if (q0 + 64 >= n_slots) ve = __shfl(total, n_slots - 1 - q0, 64);
         }
         if (lane == 0)
         {
@@ -911,6 +950,9 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         check(hipMemsetAsync(ws.bin_sum.data, 0, (size_t)count*n_bins*sizeof(double), stream),
               "bin sums");
     }
+    // (Sizing the pass by a host-side bound on the runs instead -- no wait here -- was built twice,
+    // rounds 3 and 4: the user-facing call gains 1 % at most, calls queued in numbers lose the
+    // pacing this wait gives them: profiles/r03_ab_prepass.txt, r04_ab_total_order.txt.)
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
     for (int c : ws.host_counts) max_runs = std::max(max_runs, c);

@@ -198,6 +198,8 @@ class Spectroscopy(object):
         self.farfield = bool(farfield)
         self.device_output_limit = 8 << 30     # bytes of spectra kept in HBM per block
         self.delivery_pieces = 4               # runs of tiles of the call that delivers its result
+        # "total": in which order the gases add into the one block (see _compute_levels).
+        self.total_order = "heavy_last"
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
         dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
@@ -387,6 +389,26 @@ class Spectroscopy(object):
                     total = _Sum(engine, levels, n)
                     results["total"] = engine.host_array((levels, columns))
                     kept_back = False
+                    if heavy is not None and self.total_order == "heavy_last":
+                        # The short continuum and cross-section kernels of every gas first, the
+                        # lighter gases' lines behind them, the heaviest gas last: each run of tiles
+                        # it finishes completes that part of the block, which goes to the host while
+                        # the next run computes (its pedestal pass is short since round 4, so the
+                        # first copy starts a third of the way into the call instead of behind
+                        # everything).  (Lines first and the slot kernels behind them was tried: the
+                        # slot kernels then wait for the first gas's pedestal to be applied and the
+                        # heaviest gas is queued later, 1.58 -> 1.70 ms.)
+                        for name, gas, continua_here, cross in present:
+                            slots_into(name, continua_here, cross, total, total)
+                        if not total.written:
+                            engine.fill_zero(total.buffer, asynchronous=True)
+                            total.take()
+                        for name, gas, continua_here, cross in present[1:]:
+                            if gas is not None:
+                                lines_into(name, gas, total)
+                        lines_into(heavy[0], heavy[1], total, deliver=results["total"])
+                        in_flight.append(total)
+                        present = []
                     for index, (name, gas, continua_here, cross) in enumerate(present):
                         if heavy is not None and index == 0:
                             slots_into(name, continua_here, cross, total, total)
@@ -402,6 +424,8 @@ class Spectroscopy(object):
                     if heavy is not None and kept_back:
                         engine.finish_deferred()
                         in_flight.append(total)
+                    elif self.total_order == "heavy_last" and heavy is not None:
+                        pass
                     else:
                         # (No gas with lines -- or a call the engine could not keep back, e.g.
                         # without a pedestal pass: it added at once and delivered a block that was

@@ -209,6 +209,7 @@ def test_a_failure_between_a_deferred_call_and_its_finish_leaves_nothing_behind(
     atmos = synthetic.Atmos(p=full.p, t=full.t, vmr={k: full.vmr[k] for k in ("H2O", "CO2")})
     grid = np.arange(1., 100., 0.01)
     spectroscopy = Spectroscopy(atmos, grid, database)
+    spectroscopy.total_order = "deferred"       # the heaviest gas queued first, finished last
     want = np.array(spectroscopy.compute_absorption(output_format="total")["absorption"])
     engine = spectroscopy._molecule("CO2").gas.engine
 
