@@ -126,6 +126,8 @@ struct AccumulateArgs
     int n;                          // grid points
     int v0, n_per_v;
     double dv;
+    double v0_real;                 // (double)v0: a kernel argument lives in scalar registers, the
+                                    // conversion would hold two vector registers all kernel long
     int scale_density;
     int accumulate;
     int inner_everywhere;           // 0: only the core-range lines can have inner points in a tile
@@ -750,13 +752,15 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     // register sums join it at the end.
     double * slab = &partial[wave][0][0];
     __shared__ InnerStage inner_stage[4];
+    // (The point indices as doubles: the first one converted, the others 64, 128, ... more --
+    // exact, and no integer per row stays behind in a vector register for the rest of the kernel.)
+    const double first_index = (double)(i0 + lane);
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
         // absorption.c:39: v[i] = v0 + i*dv (product rounded, then the sum).
-        const int i = i0 + p*64 + lane;
-        const double step = (double)i*a.dv;
-        v[p] = (double)a.v0 + step;
+        const double step = (first_index + (double)(p*64))*a.dv;
+        v[p] = a.v0_real + step;
         acc[p] = 0.;
     }
 
@@ -855,7 +859,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
             if (add_series)
             {
                 const int i = i0 + p*64 + lane;
-                value += series_at((double)a.v0 + (double)i*a.dv);
+                value += series_at(a.v0_real + (double)i*a.dv);
             }
             slot[p*64 + lane] = value;
         }
@@ -877,7 +881,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
                            (partial[2][p][lane] + partial[3][p][lane]);
             if (add_series)
             {
-                value += series_at((double)a.v0 + (double)i*a.dv);
+                value += series_at(a.v0_real + (double)i*a.dv);
             }
             value *= scale;
             if (a.accumulate)
@@ -895,13 +899,20 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumulateArgs a)
     accumulate_tile<P>(a);
 }
 
-// The eight-points-per-lane form (far-field series on: few lines per tile are evaluated point by
-// point, so the tile is made wide) with an occupancy hint.  Left alone the scheduler spends 108
-// VGPRs on it (4 wavefronts per SIMD); asked for 4 per SIMD or more it made do with 78 and the
-// far-field step gained 10-11 % (profiles/r03_ab_occupancy.txt); with clipped_ranges() in the
-// kernel that hint gives 82 (5 wavefronts), asked for 6 it gives 80 and another 4 %
-// (profiles/r03_ab_clipped.txt).  The same hints on P <= 4 buy nothing (71 instead of 75 VGPRs,
-// +-0 to -1 %), so those are left to the compiler.
+// Occupancy hints on the two forms that carry the benchmarks.  The eight-points-per-lane form
+// (far-field series on: few lines per tile are evaluated point by point, so the tile is made
+// wide): left alone the scheduler spends 108 VGPRs on it (4 wavefronts per SIMD); asked for 4 per
+// SIMD or more it made do with 78 and the far-field step gained 10-11 %
+// (profiles/r03_ab_occupancy.txt); with clipped_ranges() in the kernel that hint gives 82 (5
+// wavefronts), asked for 6 it gives 80 and another 4 % (profiles/r03_ab_clipped.txt).  The
+// four-points-per-lane form took the same hint in round 3 (81 VGPRs without it, one wavefront per
+// SIMD fewer) -- at the price of five registers spilled around the far-wing loop: stored and
+// re-read once per wavefront, 96 MB of scratch writes per launch on the 5 M-point workload, 70 %
+// of the kernel's HBM writes.  Round 4 removed what was spilled instead: the point indices of the
+// rows (now formed as doubles from the first one) and (double)v0 (now a kernel argument, i.e. in
+// scalar registers).  <4> compiles to 71 VGPRs without a spill (seven wavefronts per SIMD), <8> to
+// 80 with two instead of four spilled; same speed within +-1 % (profiles/r04_ab_spill.txt), where
+// the hint (6, 6) -- also free of spills, 77 VGPRs -- lost 2 %.
 template <>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6)))
 void accumulate_kernel<8>(const AccumulateArgs a)

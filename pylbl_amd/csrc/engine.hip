@@ -1392,6 +1392,7 @@ int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_fo
             args.v0 = g.v0;
             args.n_per_v = g.n_per_v;
             args.dv = g.dv;
+            args.v0_real = (double)g.v0;
             // With a pedestal the kernel stores plain sums; pedestal_apply_kernel finishes.
             args.scale_density = (!with_pedestal && (rq.flags & LBL_SCALE_DENSITY)) ? 1 : 0;
             args.accumulate = (!with_pedestal && out_device && add_into) ? 1 : 0;
