@@ -19,14 +19,18 @@ allowance for the pedestal, see test_gpu_zz_tolerance_report.py):
               O3 / CO / O2 / N2 also with.
   configs[3]  shape: 8 standard-atmosphere levels, H2O + CO2 + O3, 1-3000 @ 0.001, one batched
               call; the surface and the 10 Pa level compared at all 3 M points with pedestal on
-              and off, the levels between through windows.
+              and off, the levels between through windows.  And as the 8-GPU job cuts it: rank 0's
+              and rank 7's 8-level blocks of the 64-level atmosphere through
+              ShardedLines.for_engine, levels 0 and 63 at all points, pedestal off and on.
   configs[4]  shape: 1-5000 @ 0.0005 (n_per_v = 2000, 10 M points), 4 levels of the 256-level
               atmosphere; CO / O2 / N2 at all points with pedestal on and off at two levels; all
               eight molecules through windows at all four levels; H2O, CO2, O3, N2O and CH4 at
               all 10 M points, pedestal on and off, at one stratospheric level (level 170,
               ~1 hPa); and ONE GPU'S SHARE of the 8-GPU job -- 32 levels x 8 molecules summed on
               the device through ShardedLines.for_engine -- through windows against the
-              composition of the oracle's spectra.
+              composition of the oracle's spectra; and another rank's share WITH the pedestal
+              removed (the default through compute_absorption), one level at all 10 M points
+              against the sum of the oracle's eight spectra.
   banded      a banded CO2 table (split tiles, long pedestal chain) at 5 M points, pedestal on.
   far-field   configs[1] and the target again with the far-field series (what Spectroscopy runs
               by default), every point, pedestal on and off, same 1e-6 bar.
@@ -100,7 +104,8 @@ def farm():
             for ped in (False, True):
                 f.submit(("c4", formula, level, ped), uniform(formula), t, p, x, 1, 5001, 2000,
                          ped)
-    for formula in LARGE:
+    # (all eight at FULL_LEVEL: the composition one GPU's share is compared with, pedestal removed)
+    for formula in LARGE + SMALL:
         t, p, x = level_of(STANDARD256, formula, FULL_LEVEL)
         for ped in (False, True):
             f.submit(("c4", formula, FULL_LEVEL, ped), uniform(formula), t, p, x, 1, 5001, 2000,
@@ -301,6 +306,87 @@ def test_config4_one_gpus_share_through_the_sharded_path(engine, oracle):
             got = total[row, (lo - 1)*npv:lo*npv].cpu().numpy()
             np.testing.assert_allclose(got, expect, rtol=1e-6,
                                        err_msg=f"baseline config4 share level {96 + row} @{lo}")
+    for handle in handles.values():
+        engine.free(handle)
+
+
+def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine):
+    """The same call the way Spectroscopy.compute_absorption makes it by default
+    (spectroscopy.py:163-164: the pedestal is removed when the continuum is MT-CKD): rank 5's
+    block of the 8-GPU job (levels 160..191 x 8 molecules x 10 M points), n k summed over the
+    gases on the device with remove_pedestal=True -- every call but the first goes through the
+    un-pedestalled scratch block and pedestal_apply_kernel's adding form, on rotating lanes.  The
+    row of level 170 against the sum of the oracle's eight whole-grid spectra with the pedestal
+    removed, all 10 M points; the tolerance is the sum of the per-gas tolerances of
+    assert_spectrum."""
+    from pylbl_amd import distributed, number_density
+    formulas = SMALL + LARGE
+    plan = distributed.partition(256, [1.]*len(formulas), 8)
+    mine = distributed.level_shard(256, 5, 8)
+    assert plan.mode == "levels" and plan.levels_of(5) == list(range(mine.start, mine.stop))
+    assert mine.start <= FULL_LEVEL < mine.stop
+    t, p = STANDARD256.t[mine], STANDARD256.p[mine]
+    vmr = {f: STANDARD256.vmr[f][mine] for f in formulas}
+    tables = {f: table_from_recipe(uniform(f)) for f in formulas}
+    handles = {f: engine.load(tables[f]) for f in formulas}
+    sharded = distributed.ShardedLines.for_engine(
+        engine, handles, (1, 5001, 2000), remove_pedestal=True, scale_density=True,
+        weights=[tables[f].num_lines for f in formulas])
+    total = sharded.run(t, p, vmr, output="total")
+    assert tuple(total.shape) == (32, 10_000_000)
+    row = FULL_LEVEL - mine.start
+    got = total[row].cpu().numpy()
+    expect = np.zeros(got.size)
+    tolerance = np.zeros(got.size)
+    for f in formulas:
+        tt, pp, x = level_of(STANDARD256, f, FULL_LEVEL)
+        density = number_density(tt, pp, x)
+        k_ref = farm.result(("c4", f, FULL_LEVEL, True))[0]
+        k_plain = farm.result(("c4", f, FULL_LEVEL, False))[0]
+        expect += density*k_ref
+        tol = np.maximum(golden_io.pedestal_tolerance(k_ref, 2000, 25, 1.e-6), 1.e-6*np.abs(k_plain))
+        tol = np.maximum(tol, golden_io.pedestal_tolerance(k_plain, 2000, 25, 1.e-13))
+        tolerance += density*tol
+    worst = float(np.max(np.abs(got - expect)/(tolerance + 1e-300)))
+    assert worst <= 1., f"baseline config4 share with pedestal, level {FULL_LEVEL}: {worst:.3g} x"
+    # The other rows: finite, and the neighbours of level 170 differ from it (every level its own).
+    for other in (row - 1, row + 1, 0, 31):
+        values = total[other, ::1000].cpu().numpy()
+        assert np.all(np.isfinite(values)) and not np.array_equal(values, got[::1000])
+    for handle in handles.values():
+        engine.free(handle)
+
+
+def test_config3_blocks_of_the_64_level_job(farm, engine):
+    """configs[3] as the 8-GPU job cuts it: 64 standard-atmosphere levels, H2O + CO2 + O3,
+    1-3000 @ 0.001, 8 levels per rank.  Rank 0's and rank 7's blocks (1013 hPa ... and ... 0.1 hPa,
+    where the inner Voigt regions carry most) through ShardedLines.for_engine, per gas, pedestal
+    off and on; level 0 and level 63 -- which are the first and last of the 8-level atmosphere the
+    farm has whole-grid spectra for -- at all 3 M points."""
+    from pylbl_amd import distributed
+    formulas = ("H2O", "CO2", "O3")
+    standard64 = synthetic.standard_atmosphere(64)
+    for f in formulas:
+        for of64, of8 in ((0, 0), (63, 7)):
+            assert level_of(standard64, f, of64) == level_of(STANDARD8, f, of8)
+    tables = {f: table_from_recipe(uniform(f, 1., 3000.)) for f in formulas}
+    handles = {f: engine.load(tables[f]) for f in formulas}
+    weights = [tables[f].num_lines for f in formulas]
+    plan = distributed.partition(64, weights, 8)
+    for ped in (False, True):
+        sharded = distributed.ShardedLines.for_engine(engine, handles, (1, 3001, 1000),
+                                                      remove_pedestal=ped, weights=weights)
+        for rank, row, of8 in ((0, 0, 0), (7, 7, 7)):
+            mine = distributed.level_shard(64, rank, 8)
+            assert plan.levels_of(rank) == list(range(mine.start, mine.stop)) and \
+                mine.stop - mine.start == 8
+            vmr = {f: standard64.vmr[f][mine] for f in formulas}
+            result = sharded.run(standard64.t[mine], standard64.p[mine], vmr, output="gas")
+            for f in formulas:
+                assert tuple(result[f].shape) == (8, 3_000_000)
+                k = result[f][row].cpu().numpy()
+                check_full(farm, ("c3", f, of8, False), ("c3", f, of8, ped), k, 1, 3001, 1000,
+                           ped, f"config3 rank {rank} of 8, {f} level {mine.start + row} ped={ped}")
     for handle in handles.values():
         engine.free(handle)
 
