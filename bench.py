@@ -950,6 +950,9 @@ def run():
                 "distinct_devices": len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id"),
                                           r.get("device_index")) for r in everyone}),
                 "ranks_sharing_a_device": shared,
+                "kernels_to_exchange_ordering": "device (events between the engine's streams and "
+                                                "the exchange's, no host wait)"
+                if (args.backend == "nccl" or sharded.order_on_device) else "host (synchronize)",
                 "exchange_timeout_s": args.exchange_timeout,
                 "bytes_to_rank0_per_step": (per_rank or [{}])[0].get("bytes_received_per_step"),
                 "exchange_alone_ms_max": max((r["unoverlapped_exchange_ms"]

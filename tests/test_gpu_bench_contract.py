@@ -50,8 +50,9 @@ def test_single_gpu_line():
     assert line["pedestal_option"]["value"] > 1.e9
 
 
-@pytest.mark.parametrize("launcher", ["torch.distributed.run", "bench.py"])
-def test_two_rank_line(launcher):
+@pytest.mark.parametrize("launcher,ordering", [("torch.distributed.run", "host"),
+                                               ("bench.py", "host"), ("bench.py", "device")])
+def test_two_rank_line(launcher, ordering):
     """Under the launcher the driver's contract names, and bare (`python bench.py --gpus 2`):
     bench.py then starts its two ranks itself, as children, before anything touches the GPU."""
     with socket.socket() as s:
@@ -59,13 +60,17 @@ def test_two_rank_line(launcher):
         port = s.getsockname()[1]
     arguments = ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "1", "--steps", "2",
                  "--warmup", "1"]
+    # ordering "device": kernels and exchange ordered by events on the GPU as on the RCCL path
+    # (PYLBL_AMD_ORDER_ON_DEVICE, distributed.ShardedLines), gloo carrying the blocks.
+    environment = dict(os.environ, PYLBL_AMD_ORDER_ON_DEVICE="1" if ordering == "device" else "0")
     if launcher == "bench.py":
-        environment = {k: v for k, v in os.environ.items()
-                       if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            environment.pop(name, None)
         line = run([sys.executable] + arguments, env=environment)
     else:
         line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
-                    "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + arguments)
+                    "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + arguments,
+                   env=environment)
     check(line, 2, 2, 1)
     assert line["distributed"]["launcher"] == launcher
     assert "cpu_baseline" not in line           # rank 0 at N = 1 only
@@ -74,6 +79,7 @@ def test_two_rank_line(launcher):
     # own time, what the collection moved and what it cost.
     report = line["distributed"]
     assert report["world_size"] == 2 and report["backend"] == "gloo"
+    assert report["kernels_to_exchange_ordering"].startswith(ordering)
     assert [r["rank"] for r in report["ranks"]] == [0, 1]
     assert report["distinct_devices"] == 1 and report["ranks_sharing_a_device"]   # both on GPU 0
     n = 500000

@@ -49,14 +49,15 @@ def test_for_engine_single_rank_against_oracle(oracle, output):
     engine.close()
 
 
-def _run_ranks(n_levels, output, backend, world=2):
+def _run_ranks(n_levels, output, backend, world=2, order_on_device=False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), DIST_BACKEND=backend)
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), DIST_BACKEND=backend,
+                   PYLBL_AMD_ORDER_ON_DEVICE="1" if order_on_device else "0")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(n_levels),
              output], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -70,11 +71,15 @@ def _run_ranks(n_levels, output, backend, world=2):
         assert proc.returncode == 0 and f"rank {rank} ok" in out, out + err[-3000:]
 
 
+@pytest.mark.parametrize("ordering", ["host", "device"])
 @pytest.mark.parametrize("n_levels,output", [(5, "gas"), (1, "gas"), (1, "total"), (4, "total")])
-def test_two_ranks_share_one_gpu(n_levels, output):
+def test_two_ranks_share_one_gpu(n_levels, output, ordering):
     """Levels >= ranks shards levels; one level shards its three molecules over the two ranks
-    (and the total then needs the cross-rank sum)."""
-    _run_ranks(n_levels, output, "gloo")
+    (and the total then needs the cross-rank sum).  ordering "device": the kernels and the
+    exchange are ordered the way the RCCL path orders them -- torch's stream waits for the
+    engine's events (ShardedLines.order, lbl_order_stream_after_engine), the host does not --
+    with gloo carrying the blocks: what is left untested for the 8-GPU box is RCCL's transport."""
+    _run_ranks(n_levels, output, "gloo", order_on_device=(ordering == "device"))
 
 
 def _visible_gpus():
