@@ -400,6 +400,17 @@ struct lbl_engine
     int device = 0;
     hipStream_t stream = nullptr;   // == lanes[0].main: uploads, and what lbl_stream() returns
     hipStream_t copy_stream = nullptr;  // results on their way to host memory
+    // The runtime multiplexes its streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4
+    // by default) in an order of its own, and a queue runs its packets one after the other: a copy
+    // that shares its queue with the main stream of the lane that is computing waits for that
+    // lane's accumulate launches instead of running beside them.  For the call that delivers its
+    // result piece by piece that was 1.9 against 1.6 ms (Spectroscopy's "total"), decided by
+    // nothing but which lane the call had been dealt (profiles/r04_copy_streams.txt).  The engine
+    // asks the GPU once, when it is created, which lanes share a queue with the copy stream
+    // (calibrate_delivery_lanes), and a delivering call skips those.  (One copy stream per lane,
+    // each chosen to run beside it, was tried first: slower than the best single one -- every
+    // further stream in use is one more queue for the hardware to take turns on.)
+    bool delivers_badly[kLanes] = {};
     hipEvent_t copies_handed_over = nullptr, taken_over = nullptr;  // lbl_order_*_after_*
     std::string error;
     std::vector<std::unique_ptr<Molecule>> molecules;
@@ -425,6 +436,7 @@ struct lbl_engine
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
+    int skip_delivery_lanes = 1;    // delivering calls avoid lanes that share the copy stream's queue
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };
@@ -1129,6 +1141,17 @@ int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_fo
             {
                 lane_index = (int)(engine->next_lane++ % rotate);
             }
+            // A call that delivers its result while it computes: not on a lane whose accumulate
+            // launches would hold up its copies (see delivers_badly).
+            for (int tries = 1; tries < rotate && rq.host != nullptr && out_device &&
+                                engine->skip_delivery_lanes && engine->delivers_badly[lane_index];
+                 ++tries)
+            {
+                const int next = (int)(engine->next_lane % rotate);
+                if (&engine->lanes[next] == engine->deferred) break;
+                lane_index = next;
+                engine->next_lane += 1;
+            }
         }
         Lane & lane = engine->lanes[lane_index];
         hipStream_t stream = lane.main;
@@ -1677,6 +1700,44 @@ int locked_compute(lbl_engine * engine, const ComputeRequest & rq)
     return status;
 }
 
+// Spins for about `ticks` of the constant-rate clock (100 MHz): something that keeps a queue busy.
+__global__ void spin_kernel(long long ticks, int * sink)
+{
+    const long long begin = wall_clock64();
+    int turns = 0;
+    while (wall_clock64() - begin < ticks && turns < (1 << 26)) turns += 1;
+    if (sink != nullptr && turns < 0) *sink = turns;
+}
+
+__global__ void touch_kernel() {}
+
+// Which lanes' main streams share a hardware queue with the copy stream (lbl_engine::
+// delivers_badly): the lane's main stream is kept busy for ~40 us, an empty kernel goes to the copy
+// stream, and if that only gets through when the lane is done, the two are one queue.
+void calibrate_delivery_lanes(lbl_engine * e)
+{
+    hipEvent_t lane_done, through;
+    HIP_TRY(hipEventCreate(&lane_done));
+    HIP_TRY(hipEventCreate(&through));
+    const long long ticks = 4000;       // 40 us at 100 MHz
+    for (int l = 0; l < kLanes; ++l)
+    {
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, e->lanes[l].main, ticks,
+                           (int *)nullptr);
+        HIP_TRY(hipEventRecord(lane_done, e->lanes[l].main));
+        hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, e->copy_stream);
+        HIP_TRY(hipEventRecord(through, e->copy_stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(lane_done));
+        HIP_TRY(hipEventSynchronize(through));
+        float ahead = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ahead, through, lane_done));
+        e->delivers_badly[l] = !(ahead > 0.01f);
+    }
+    (void)hipEventDestroy(lane_done);
+    (void)hipEventDestroy(through);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1708,6 +1769,7 @@ int lbl_engine_create(int device, lbl_engine ** engine)
         for (int i = 0; i < kAllLanes; ++i) e->lanes[i].create(i == kSlotLane);
         e->stream = e->lanes[0].main;
         HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        calibrate_delivery_lanes(e.get());
         HIP_TRY(hipEventCreateWithFlags(&e->copies_handed_over, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->taken_over, hipEventDisableTiming));
         *engine = e.release();
@@ -2018,6 +2080,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "order_runs" && (value == 0 || value == 1))
     {
         engine->order_runs = (int)value;
+    }
+    else if (key == "skip_delivery_lanes" && (value == 0 || value == 1))
+    {
+        engine->skip_delivery_lanes = (int)value;
     }
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
