@@ -1062,6 +1062,13 @@ def run():
                 "far-field series) and their accumulate kernels overlap, so achieved / frac / "
                 "avg_launch_ms come from the same launches run alone after the timed region "
                 "(blocking calls); avg_launch_ms_overlapped_in_step is what the events read inside it")
+        if args.farfield:
+            # The series replaces most evaluations by one polynomial per point: "7 flops per eval x
+            # evals" is not what the kernel executes, and the quotient is not a fraction of a peak.
+            line["roofline"]["frac"] = None
+            line["roofline"]["note"] += ("; far-field series on: most of the evaluations counted in "
+                                         "`value` are not executed one by one, so `achieved` is not "
+                                         "a rate of executed flops and no fraction is given")
         if args.host_output:
             line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
         if args.ablate:
@@ -1081,9 +1088,10 @@ def run():
         if leg("pedestal") and not args.pedestal:
             line["pedestal_option"] = lines_leg(
                 engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
-                remove_pedestal=True,
+                remove_pedestal=True, ring=2,
                 label="same workload with remove_pedestal=True (the default through "
-                      "compute_absorption, spectroscopy.py:163-164)")
+                      "compute_absorption, spectroscopy.py:163-164), two sets of output blocks "
+                      "used in turn like the timed step's")
         if leg("atmosphere"):
             standard = synthetic.standard_atmosphere(8)
             line["standard_atmosphere_option"] = lines_leg(
