@@ -20,4 +20,7 @@ python bench.py --steps 3 --warmup 1 --config 4 --levels-per-gpu 32 --profile st
 echo "shares done"
 python bench.py --steps 10 --warmup 3 --host-output --no-extras > $O/bench_${TAG}_host_output.json 2>> $O/bench_${TAG}.err || exit 1
 MASTER_PORT=29517 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 > $O/bench_${TAG}_gloo2.json 2>> $O/bench_${TAG}.err || exit 1
+# the bare form (bench.py starts its two ranks itself), kernels and exchange ordered on the device
+PYLBL_AMD_ORDER_ON_DEVICE=1 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 > $O/bench_${TAG}_gloo2_bare.json 2>> $O/bench_${TAG}.err || exit 1
+python bench.py --steps 20 --warmup 5 --farfield --pedestal --no-extras > $O/bench_${TAG}_farfield_pedestal.json 2>> $O/bench_${TAG}.err || exit 1
 echo "all done"
