@@ -97,6 +97,8 @@ def parse():
     parser.add_argument("--launch-timeout", type=float, default=1500.,
                         help="bare `bench.py --gpus N` (no launcher, N > 1): seconds the N child "
                              "ranks may take before they are ended and the run reported failed")
+    parser.add_argument("--launch-grace", type=float, default=5.,
+                        help="bare launch: seconds the other ranks get to report after one has failed")
     parser.add_argument("--ablate", type=int, default=0,
                         help="diagnostics: 1 skips the general ranges, 2 the fast ranges "
                              "(results are wrong; the line is marked invalid)")
@@ -594,7 +596,7 @@ def device_identity(torch, index):
     return out
 
 
-def launch_ranks(args):
+def launch_ranks(args, command=None):
     """`python bench.py --gpus N` with no launcher around it: starts the N ranks as CHILD
     processes (what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1` would start: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
@@ -618,7 +620,8 @@ def launch_ranks(args):
                  "PYLBL_BENCH_LAUNCHER": "bench.py"})
     base.setdefault("OMP_NUM_THREADS", "1")             # as torch.distributed.run does
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs here
-    command = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if command is None:             # (tests pass a stand-in for the ranks' program)
+        command = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     children, relays = [], []
 
     def relay(stream, target, prefix):
@@ -654,6 +657,7 @@ def launch_ranks(args):
 
     deadline = time.monotonic() + args.launch_timeout
     reason = None
+    own = []            # exit codes of the ranks that left by themselves
     while True:
         codes = [child.poll() for child in children]
         if all(code is not None for code in codes):
@@ -664,9 +668,10 @@ def launch_ranks(args):
         elif time.monotonic() > deadline:
             reason = f"no result after --launch-timeout {args.launch_timeout:g} s"
         if reason:
-            time.sleep(5.)                    # let the others print what they were doing
+            time.sleep(args.launch_grace)     # let the others print what they were doing
+            own = [code for code in (child.poll() for child in children) if code is not None]
             stop(signal.SIGTERM)
-            time.sleep(3.)
+            time.sleep(min(3., args.launch_grace))
             stop(signal.SIGKILL)
             for child in children:
                 child.wait()
@@ -675,11 +680,15 @@ def launch_ranks(args):
     for thread in relays:
         thread.join(timeout=5.)
     codes = [child.returncode for child in children]
-    worst = max((128 - code if code < 0 else code) for code in codes)
+    if not reason:
+        own = codes
+    # The worst code among the ranks that left by themselves (the ones this launcher ended do not
+    # count); 124, like timeout(1), when time ran out with none of them having failed.
+    worst = max([(128 - code if code < 0 else code) for code in own] or [0])
     if reason:
         print(json.dumps({"bench_failed": True, "launcher": True, "reason": reason,
                           "exit_codes": codes}), file=sys.stderr, flush=True)
-        worst = worst or 1
+        worst = worst or (124 if "launch-timeout" in reason else 1)
     return worst
 
 

@@ -289,3 +289,69 @@ def test_bench_starts_its_own_ranks_and_reports_the_worst_exit_code():
     assert len(refusals) == 2
     report = json.loads([x for x in result.stderr.splitlines() if x.startswith("{")][-1])
     assert report["bench_failed"] and report["launcher"] and report["exit_codes"] == [1, 1]
+
+
+def _launch(tmp_path, body, gpus=3, timeout=30., grace=0.3):
+    """bench.launch_ranks over a stand-in for the ranks' program (no GPU needed): returns
+    (exit code, what the launcher relayed on stdout, on stderr)."""
+    import subprocess
+    import sys
+    import textwrap
+    child = tmp_path / "rank.py"
+    child.write_text(textwrap.dedent(body))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import argparse, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        args = argparse.Namespace(gpus={gpus}, launch_timeout={timeout}, launch_grace={grace})
+        sys.exit(bench.launch_ranks(args, command=[sys.executable, {str(child)!r}]))
+        """))
+    environment = {k: v for k, v in __import__("os").environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    result = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True,
+                            env=environment, timeout=120)
+    return result.returncode, result.stdout, result.stderr
+
+
+def test_bench_launcher_relays_rank_zero_and_hands_every_rank_its_place(tmp_path):
+    """What `python bench.py --gpus N` does without a launcher around it: N children with RANK,
+    LOCAL_RANK, WORLD_SIZE and one MASTER_ADDR / MASTER_PORT, rank 0's stdout relayed as it is,
+    the others' on stderr with their rank, exit code 0 when all leave with 0."""
+    code, out, err = _launch(tmp_path, """
+        import json, os
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_WORLD_SIZE"] == str(world)
+        print(json.dumps({"rank": rank, "n_gpus": world, "port": os.environ["MASTER_PORT"]}))
+        """)
+    import json
+    assert code == 0, err
+    lines = [json.loads(x) for x in out.strip().splitlines()]
+    assert lines == [{"rank": 0, "n_gpus": 3, "port": lines[0]["port"]}]
+    others = sorted(x for x in err.splitlines() if x.startswith("[rank "))
+    assert [x.split("]")[0] for x in others] == ["[rank 1", "[rank 2"]
+    assert all(json.loads(x.split("] ", 1)[1])["port"] == lines[0]["port"] for x in others)
+
+
+def test_bench_launcher_ends_the_others_when_a_rank_fails_or_time_runs_out(tmp_path):
+    """A rank that leaves with 3 (bench.py's code for an exchange that timed out) ends ranks that
+    would wait for ever, and 3 is what the launcher returns; --launch-timeout ends all of them."""
+    import json
+    import time
+    start = time.perf_counter()
+    code, out, err = _launch(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            time.sleep(0.5)
+            sys.exit(3)
+        time.sleep(600)
+        """)
+    assert code == 3 and time.perf_counter() - start < 60.
+    report = json.loads([x for x in err.splitlines() if x.startswith("{")][-1])
+    assert report["launcher"] and report["reason"] == "rank 1 left with code 3"
+    assert report["exit_codes"][1] == 3 and all(c < 0 for i, c in enumerate(report["exit_codes"])
+                                                 if i != 1)          # ended by a signal
+    code, out, err = _launch(tmp_path, "import time; time.sleep(600)", gpus=2, timeout=1.)
+    report = json.loads([x for x in err.splitlines() if x.startswith("{")][-1])
+    assert code != 0 and "launch-timeout" in report["reason"]
