@@ -539,7 +539,49 @@ def test_output_of_molecule_without_data_is_zeroed(small_database):
                                 asynchronous=True)
     gas.engine.synchronize()
     assert not block.to_host().any()
+    # deliver=: the page-locked view the caller was promised reads what the block reads -- zeros,
+    # or (accumulating) what the earlier calls left there -- not its stale contents.
+    view = gas.engine.host_array((2, grid.size))
+    view[...] = -7.
+    gas.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-7, 3e-7], grid, out=block,
+                                asynchronous=True, deliver=view)
+    gas.engine.synchronize()
+    assert not view.any()
+    other.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-4, 3e-4], grid, out=block)
+    view[...] = -7.
+    gas.absorption_coefficients([250., 260.], [5e4, 6e4], [3e-7, 3e-7], grid, out=block,
+                                accumulate=True, asynchronous=True, deliver=view)
+    gas.engine.synchronize()
+    assert np.array_equal(view, kept[:, :grid.size])
     block.free()
+
+
+def test_delivery_does_not_depend_on_the_lane(oracle):
+    """A call that delivers its result while it computes skips the lanes whose stream shares the
+    copy stream's hardware queue (engine option skip_delivery_lanes, probed when the engine is
+    created): a matter of speed only -- with the option on or off, and whichever lane the call is
+    dealt, block and delivered array are those of the plain call."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CO2", 1., 130., num_lines=6000, seed=18, tips_range=(150, 400))
+    handle = e.load(table)
+    atmos = synthetic.standard_atmosphere(2)
+    v0, vn, npv = 1, 101, 500
+    n = (vn - v0)*npv
+    plain = e.compute(handle, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True)
+    block = DeviceSpectra(e, 2, n)
+    for skip in (1, 0):
+        e.set_option("skip_delivery_lanes", skip)
+        for turn in range(6):            # every lane of the rotation, some of them skipped
+            target = e.host_array((2, n - 100))
+            target[...] = -1.
+            e.compute(handle, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True,
+                      out=block, asynchronous=True, deliver=target, pieces=4)
+            e.synchronize()
+            assert np.array_equal(block.to_host(), plain), (skip, turn)
+            assert np.array_equal(target, plain[:, :n - 100]), (skip, turn)
+    block.free()
+    e.close()
 
 
 def test_asynchronous_pedestal_calls_into_one_buffer_are_ordered():
