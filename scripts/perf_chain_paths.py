@@ -1,4 +1,4 @@
-"""Pedestal pass time with the scan chain on/off for uniform and banded tables (one process)."""
+"""Pedestal pass time with the parallel chain (relaxation) on/off for uniform and banded tables (one process)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
