@@ -58,18 +58,21 @@ struct RunMeta
     int pad;
 };
 
+constexpr int kLinkWords = 4;       // history visible to a run: the previous 64 kLinkWords runs
+constexpr int kLinkReach = 64*kLinkWords;
+
 struct alignas(16) RunLink
 {
     double ks;          // GS + VS: first-slot candidate before subtracting earlier pedestals
     double ke;          // GE + VE: last-slot candidate
-    unsigned long long mask_s[2];   // bit j of word h: run r-1-j-64h holds this run's first slot
-    unsigned long long mask_e[2];   // ... this run's last slot
+    unsigned long long mask_s[kLinkWords];  // bit j of word h: run r-1-j-64h holds this run's first slot
+    unsigned long long mask_e[kLinkWords];  // ... this run's last slot
     int bin;            // the run's window (RunMeta::bin)
     int next_same;      // the next run with the same bin, -1 if none
     int n_slots;
     int first_of_bin;   // 1: no earlier run has this bin
 };
-static_assert(sizeof(RunLink) == 64, "RunLink");
+static_assert(sizeof(RunLink) == 32 + 16*kLinkWords, "RunLink");
 
 template <typename T>
 struct RawBuffer
@@ -423,7 +426,9 @@ __device__ __forceinline__ double read_lane(double value, int lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-constexpr int kLinkReach = 128;     // history visible to a run: the previous 128 runs
+// (kLinkReach = 256 runs of history: a uniform 400 k-line table at 1 atm needs 63 -- one run per
+// window plus a few where shifted lines alternate between two windows -- the same lines in eight
+// Gaussian bands 177.)
 
 // Per level: [0] 1 while the parallel chain applies (cleared by run_links_kernel where a window
 // reaches back beyond kLinkReach runs), [1] / [2] something changed in the second / third
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
         RunLink link;
         double gs = 0., ge = 0.;
         bool seen_before = false;
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < kLinkWords; ++half)
         {
             const int q = r - 1 - half*64 - lane;
             bool holds_s = false, holds_e = false;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
             ge += __shfl_xor(ge, offset, 64);
         }
         int next = -1;
-        for (int half = 0; half < 2 && next < 0; ++half)
+        for (int half = 0; half < kLinkWords && next < 0; ++half)
         {
             const int q = r + 1 + half*64 + lane;
             const unsigned long long same = __ballot(q < count && meta[min(q, count - 1)].bin == m.bin);
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
                                                        int * __restrict__ state,
                                                        double * __restrict__ bin_sum)
 {
-    __shared__ double history[kLinkReach];      // P of runs base-128 ... base-1 (previous launch)
+    __shared__ double history[kLinkReach];      // P of runs base-256 ... base-1 (previous launch)
     const int level = blockIdx.y;
     const int lane = threadIdx.x;
     const int count = run_count[level];
@@ -586,37 +591,46 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
     const bool valid = r < count;
     RunLink mine;
     mine.ks = mine.ke = 0.;
-    mine.mask_s[0] = mine.mask_s[1] = mine.mask_e[0] = mine.mask_e[1] = 0ull;
+    for (int h = 0; h < kLinkWords; ++h) mine.mask_s[h] = mine.mask_e[h] = 0ull;
     mine.bin = -1; mine.next_same = -1; mine.n_slots = 0; mine.first_of_bin = 0;
     if (valid) mine = link[r];
+    static_assert(kLinkWords == 4, "the word of a bit is chosen by comparisons below");
     const unsigned long long mask_s0 = mine.mask_s[0], mask_s1 = mine.mask_s[1];
+    const unsigned long long mask_s2 = mine.mask_s[2], mask_s3 = mine.mask_s[3];
     const unsigned long long mask_e0 = mine.mask_e[0], mask_e1 = mine.mask_e[1];
+    const unsigned long long mask_e2 = mine.mask_e[2], mask_e3 = mine.mask_e[3];
     double given = 0.;
     // Sums over the runs of earlier chunks: bit j of a mask is run r-1-j, history entry t is run
-    // base-128+t, so entry t is bit lane+127-t.  Oldest first; entries no lane names are skipped.
+    // base-256+t, so entry t is bit lane+255-t.  Oldest first; entries no lane names are skipped.
     double before_s = 0., before_e = 0.;
     if (step > 0 && base > 0)
     {
-        history[lane] = base - 128 + lane >= 0 ? from[base - 128 + lane] : 0.;
-        history[64 + lane] = base - 64 + lane >= 0 ? from[base - 64 + lane] : 0.;
+        for (int h = 0; h < kLinkWords; ++h)
+        {
+            const int q = base - kLinkReach + 64*h + lane;
+            history[64*h + lane] = q >= 0 ? from[q] : 0.;
+        }
         __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
+        const unsigned long long any3 = mask_s3 | mask_e3, any2 = mask_s2 | mask_e2;
         const unsigned long long any1 = mask_s1 | mask_e1, any0 = mask_s0 | mask_e0;
-        const int top_bit = any1 ? 127 - __builtin_clzll(any1) : any0 ? 63 - __builtin_clzll(any0) : -1;
-        int oldest = top_bit >= lane ? lane + 127 - top_bit : 128;
+        const int top_bit = any3 ? 255 - __builtin_clzll(any3) : any2 ? 191 - __builtin_clzll(any2)
+                            : any1 ? 127 - __builtin_clzll(any1) : any0 ? 63 - __builtin_clzll(any0) : -1;
+        int oldest = top_bit >= lane ? lane + kLinkReach - 1 - top_bit : kLinkReach;
         for (int offset = 32; offset > 0; offset >>= 1)
         {
             oldest = min(oldest, __shfl_xor(oldest, offset, 64));
         }
-        for (int t = max(oldest, 0); t < 128; ++t)
+        for (int t = max(oldest, 0); t < kLinkReach; ++t)
         {
             const double value = history[t];
-            const int j = lane + 127 - t;           // 64 <= j for the lanes that can name it
-            const bool far = j >= 64;
-            const unsigned long long word_s = far ? mask_s1 : mask_s0;
-            const unsigned long long word_e = far ? mask_e1 : mask_e0;
+            const int j = lane + kLinkReach - 1 - t;    // lane <= j: the runs of earlier chunks
+            const unsigned long long word_s = j < 128 ? (j < 64 ? mask_s0 : mask_s1)
+                                                      : (j < 192 ? mask_s2 : mask_s3);
+            const unsigned long long word_e = j < 128 ? (j < 64 ? mask_e0 : mask_e1)
+                                                      : (j < 192 ? mask_e2 : mask_e3);
             const int shift = j & 63;
-            if (j < 128 && ((word_s >> shift) & 1ull)) before_s += value;
-            if (j < 128 && ((word_e >> shift) & 1ull)) before_e += value;
+            if (j < kLinkReach && ((word_s >> shift) & 1ull)) before_s += value;
+            if (j < kLinkReach && ((word_e >> shift) & 1ull)) before_e += value;
         }
     }
     if (step > 0 && valid) given = from[r];
