@@ -968,7 +968,10 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     }
     // (Sizing the pass by a host-side bound on the runs instead -- no wait here -- was built twice,
     // rounds 3 and 4: the user-facing call gains 1 % at most, calls queued in numbers lose the
-    // pacing this wait gives them: profiles/r03_ab_prepass.txt, r04_ab_total_order.txt.)
+    // pacing this wait gives them: profiles/r03_ab_prepass.txt, r04_ab_total_order.txt.  Reading the
+    // counts back into page-locked instead of pageable memory, so that the copy in
+    // pedestal_find_runs does not hold the host either: 0 ... -4 % on the same legs,
+    // profiles/r04_ab_pinned_counts.txt.)
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
     for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
