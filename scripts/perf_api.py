@@ -21,6 +21,9 @@ grid = np.arange(1., 5000., 0.001)
 if os.environ.get("LANES"):
     from pylbl_amd.engine import default_engine
     default_engine(0).set_option("lanes", int(os.environ["LANES"]))
+if os.environ.get("POINTS_PER_LANE"):
+    from pylbl_amd.engine import default_engine
+    default_engine(0).set_option("points_per_lane", int(os.environ["POINTS_PER_LANE"]))
 for farfield in (True, False):
     spec = Spectroscopy(level, grid, MemoryDatabase(tables), farfield=farfield)
     for count in pieces:
