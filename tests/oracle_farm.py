@@ -17,7 +17,8 @@ import numpy as np
 @functools.lru_cache(maxsize=None)
 def table_from_recipe(recipe):
     """recipe: ("uniform", formula, v_lo, v_hi) -> synthetic.line_table(formula, v_lo, v_hi);
-    ("banded", formula, v_lo, v_hi, num_lines, bands, seed) -> synthetic.banded_line_table."""
+    ("banded", formula, v_lo, v_hi, num_lines, bands, seed) -> synthetic.banded_line_table;
+    ("hitran", v_lo, v_hi, num_lines, seed) -> tests.hitran_shapes.hitran_shaped_table."""
     from pylbl_amd import synthetic
     kind = recipe[0]
     if kind == "uniform":
@@ -27,6 +28,10 @@ def table_from_recipe(recipe):
         _, formula, v_lo, v_hi, num_lines, bands, seed = recipe
         return synthetic.banded_line_table(formula, v_lo, v_hi, num_lines=num_lines,
                                            bands=bands, seed=seed)
+    if kind == "hitran":
+        from tests.hitran_shapes import hitran_shaped_table
+        _, v_lo, v_hi, num_lines, seed = recipe
+        return hitran_shaped_table(np.random.default_rng(seed), v_lo, v_hi, num_lines)
     raise ValueError(f"unknown table recipe {recipe!r}")
 
 

@@ -32,6 +32,10 @@ allowance for the pedestal, see test_gpu_zz_tolerance_report.py):
               removed (the default through compute_absorption), one level at all 10 M points
               against the sum of the oracle's eight spectra.
   banded      a banded CO2 table (split tiles, long pedestal chain) at 5 M points, pedestal on.
+  HITRAN-shaped  a 150 000-line table with the corner values real tables have (zero half-widths,
+              n_air <= 0, elower = -1, positions down to 1e-4 cm-1, twelve isotopologues:
+              tests/hitran_shapes.py) on 0-5000 @ 0.001, all 5 M points, pedestal off and on,
+              direct and with the far-field series.
   far-field   configs[1] and the target again with the far-field series (what Spectroscopy runs
               by default), every point, pedestal on and off, same 1e-6 bar.
   end to end  Spectroscopy.compute_absorption() with default arguments at 5 M points, one
@@ -60,6 +64,8 @@ SMALL = ("CO", "O2", "N2")
 LARGE = ("H2O", "CO2", "O3", "N2O", "CH4")
 FULL_LEVEL = 170
 BANDED = ("banded", "CO2", 1., 5000., 300_000, 8, 41)
+HITRAN_SHAPED = ("hitran", 1.e-4, 5026., 150_000, 8101)
+HITRAN_LEVEL = (250., 5.e4, 4.e-4)
 
 
 def uniform(formula, v_lo=1., v_hi=5000.):
@@ -114,6 +120,9 @@ def farm():
     t, p, x = level_of(SURFACE, "CO2", 0)
     for ped in (False, True):
         f.submit(("banded", ped), BANDED, t, p, x, 1, 5001, 1000, ped)
+    # HITRAN-shaped values at the target's size
+    for ped in (False, True):
+        f.submit(("hitran", ped), HITRAN_SHAPED, *HITRAN_LEVEL, 0, 5000, 1000, ped)
     f.start()
     yield f
     f.close()
@@ -480,3 +489,20 @@ def test_banded_table_whole_grid_pedestal(farm, engine):
         check_full(farm, ("banded", False), ("banded", ped), k[0], 1, 5001, 1000, ped,
                    f"banded CO2 ped={ped}", evals)
     engine.free(handle)
+
+
+@pytest.mark.parametrize("farfield", [False, True])
+def test_hitran_shaped_table_whole_grid(farm, engine, farfield):
+    """What tests/test_gpu_fuzz_hitran.py checks on small grids, at the size bench.py times: every
+    one of 5 M points against the oracle (spectra.c:17-62, voigt.c:17-53), pedestal off and on."""
+    table = table_from_recipe(HITRAN_SHAPED)
+    molecule = engine.load(table)
+    t, p, x = HITRAN_LEVEL
+    try:
+        for ped in (False, True):
+            k = engine.compute(molecule, t, p, x, 0, 5000, 1000, remove_pedestal=ped,
+                               farfield=farfield)[0]
+            check_full(farm, ("hitran", False), ("hitran", ped), k, 0, 5000, 1000, ped,
+                       f"hitran-shaped farfield={farfield} ped={ped}")
+    finally:
+        engine.free(molecule)
