@@ -667,6 +667,11 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
 }
 
 constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at a time
+// Small-LDS form: the slots of the spectrum live in HBM, kChainRing consecutive ones of them in LDS
+// (the register window moves inside that ring at the price of an LDS round trip; only when it
+// leaves the ring -- every ~380 bins of a sorted table -- does the chain wait for HBM).
+constexpr int kChainRing = 512;
+constexpr int kChainRingBack = 64;  // slots kept behind the window that re-bases the ring
 
 // One wavefront per level: the serial recurrence over runs.  Slots (the accumulated
 // spectrum on integer wavenumbers) and the per-window pedestal totals live in LDS; the
@@ -732,6 +737,15 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
     }
     int zone = 0;           // WINDOW: first slot held in registers
     double window = 0.;     // WINDOW: slot zone + lane (all slots start at zero)
+    // !USE_LDS && WINDOW: slots [ring_base, ring_base + kChainRing) are current in `ring`, the
+    // others in HBM.
+    double * ring = lds + 2*kChainChunk*slot_stride;
+    int ring_base = 0;
+    if (!USE_LDS && WINDOW)
+    {
+        for (int s = lane; s < kChainRing; s += 64) ring[s] = 0.;
+        __syncthreads();
+    }
     for (int base = 0; base < count; base += kChainChunk)
     {
         const int chunk = min(kChainChunk, count - base);
@@ -770,10 +784,39 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
                 // registers with v_readlane, the update is one masked vector add.
                 if (first_slot < zone || last_slot > zone + 63)
                 {
-                    if (zone + lane <= n_cells) a[zone + lane] = window;
-                    if (USE_LDS) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-                    zone = first_slot;
-                    window = zone + lane <= n_cells ? a[zone + lane] : 0.;
+                    if (USE_LDS)
+                    {
+                        if (zone + lane <= n_cells) a[zone + lane] = window;
+                        __builtin_amdgcn_wave_barrier();
+                        zone = first_slot;
+                        window = zone + lane <= n_cells ? a[zone + lane] : 0.;
+                    }
+                    else
+                    {
+                        ring[(zone + lane) & (kChainRing - 1)] = window;
+                        __builtin_amdgcn_wave_barrier();
+                        if (first_slot < ring_base || first_slot + 63 >= ring_base + kChainRing)
+                        {
+                            // The ring goes back to HBM and is filled again around the new window.
+#pragma unroll
+                            for (int k = 0; k < kChainRing/64; ++k)
+                            {
+                                const int slot = ring_base + k*64 + lane;
+                                if (slot <= n_cells) a[slot] = ring[slot & (kChainRing - 1)];
+                            }
+                            __syncthreads();
+                            ring_base = max(first_slot - kChainRingBack, 0);
+#pragma unroll
+                            for (int k = 0; k < kChainRing/64; ++k)
+                            {
+                                const int slot = ring_base + k*64 + lane;
+                                ring[slot & (kChainRing - 1)] = slot <= n_cells ? a[slot] : 0.;
+                            }
+                            __syncthreads();
+                        }
+                        zone = first_slot;
+                        window = ring[(zone + lane) & (kChainRing - 1)];
+                    }
                 }
                 const int f = first_slot - zone, e = last_slot - zone;
                 const bool interior = lane > f && lane < e;
@@ -851,7 +894,7 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
         }
         __syncthreads();
     }
-    if (WINDOW && zone + lane <= n_cells) a[zone + lane] = window;
+    if (WINDOW && USE_LDS && zone + lane <= n_cells) a[zone + lane] = window;
     __syncthreads();
     if (USE_LDS)
     {
@@ -1010,6 +1053,7 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     // ones in registers): it usually only looks at the flags and returns, and must not queue for
     // most of a CU's LDS to do that (the accumulate workgroups beside it hold 12-27 KB each).
     const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
+    const size_t ring_bytes = (size_t)kChainRing*sizeof(double);
     const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
     if (lds_bytes <= 160*1024 - 512 && !parallel_chain)
     {
@@ -1033,7 +1077,7 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     {
         ws.slots.reserve((size_t)count*(n_cells + 1));
         auto chain = slot_stride <= 64 ? run_chain_kernel<false, true> : run_chain_kernel<false, false>;
-        hipLaunchKernelGGL(chain, dim3(count), dim3(64), staged_bytes, stream,
+        hipLaunchKernelGGL(chain, dim3(count), dim3(64), staged_bytes + ring_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
                            ws.runs.data, ws.slot_sums.data, ws.state.data, ws.slots.data,
                            ws.bin_sum.data);
