@@ -738,8 +738,12 @@ int pick_tiling(const lbl_engine * engine, int farfield, int n_per_v, long long 
     if (!is_forced)
     {
         // Measured on the 0.001 cm-1 workload: 4 is ~2 % ahead of 8 for the direct kernel,
-        // 8 is ahead when the far-field series carries most lines.
-        p = (n_per_v >= 400 && farfield) ? 8 : n_per_v >= 100 ? 4 : n_per_v >= 10 ? 2 : 1;
+        // 8 is ahead when the far-field series carries most lines.  With the series a tile does
+        // best at 0.5-1.3 cm-1 (the lines within four half-widths stay with the direct kernel):
+        // at 0.01 cm-1 two points per lane, 0.467 -> 0.423 ms per step
+        // (profiles/r04_farfield_small_grids.txt).
+        p = (n_per_v >= 400 && farfield) ? 8 : (n_per_v >= 100 && farfield) ? 2
+            : n_per_v >= 100 ? 4 : n_per_v >= 10 ? 2 : 1;
     }
     tiling.aligned = 0;
     tiling.per_cell = 0;
