@@ -1103,8 +1103,16 @@ int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_fo
 
     Tiling tiling;
     // The far-field series: an engine-wide option, or this call's choice (LBL_FARFIELD).
-    const int farfield = (engine->farfield || (rq.flags & LBL_FARFIELD)) ? 1 : 0;
-    const int points = pick_tiling(engine, farfield, rq.n_per_v, n_long, tiling);
+    int farfield = (engine->farfield || (rq.flags & LBL_FARFIELD)) ? 1 : 0;
+    int points = pick_tiling(engine, farfield, rq.n_per_v, n_long, tiling);
+    if (farfield && kFarRatio*0.5*(double)tiling.length >= (double)rq.cut_off*rq.n_per_v)
+    {
+        // A tile so wide (coarse grids: 0.1 cm-1 and up) that no line of a window is kFarRatio
+        // half-widths away: the series would sum nothing and its two kernels only cost their
+        // launches (configs[0]: 0.033 -> 0.041 ms per step, profiles/r04_farfield_small_grids.txt).
+        farfield = 0;
+        points = pick_tiling(engine, farfield, rq.n_per_v, n_long, tiling);
+    }
     const int n_tiles = tiling.n_tiles;
     const int n_cells = rq.vn - rq.v0;
     const bool out_device = (rq.flags & LBL_OUT_DEVICE) != 0;
