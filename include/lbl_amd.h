@@ -66,7 +66,9 @@ extern "C" {
 #define LBL_FARFIELD       16   /* this call: lines at least 4 tile half-widths away (and beyond
                                    every line core) enter through one power series per tile
                                    instead of point by point -- truncation <= ~1.5e-11 relative,
-                                   3-4x faster at 0.001 cm-1 (same as option "farfield" = 1)  */
+                                   3-4x faster at 0.001 cm-1 (same as option "farfield" = 1);
+                                   on grids so coarse that a tile is as wide as a line's window
+                                   (0.1 cm-1 and up) nothing is far and the call runs without  */
 #define LBL_DEFER_FINISH   32   /* with LBL_ASYNC | LBL_OUT_DEVICE and remove_pedestal: everything
                                  * is queued except the last kernels, which apply the pedestal
                                  * to k (and the copies of lbl_compute_streamed): those wait for
