@@ -15,6 +15,7 @@ of numpy arrays with the same variable names.
 """
 from collections import namedtuple
 import contextlib
+import os
 
 import numpy as np
 
@@ -200,6 +201,9 @@ class Spectroscopy(object):
         self.delivery_pieces = 4               # runs of tiles of the call that delivers its result
         # "total": in which order the gases add into the one block (see _compute_levels).
         self.total_order = "heavy_last"
+        # "gas": "each" -- every gas's lines call delivers its block piece by piece; "last" -- only
+        # the last gas does, the others' blocks travel in one copy each.
+        self.gas_delivery = os.environ.get("PYLBL_AMD_GAS_DELIVERY", "each")
         Output = namedtuple("Output", ["dims", "dim_sizes", "mechanisms", "units"])
         dims = list(self.atmosphere.dims) + ["mechanism", "wavenumber"]
         dim_sizes = list(self.atmosphere.temperature.shape) + [len(MECHANISMS), self.grid.size]
@@ -438,7 +442,7 @@ class Spectroscopy(object):
                         if mode == "gas":
                             block = _Sum(engine, levels, n)
                             results[name] = engine.host_array((levels, columns))
-                            if gas is not None and last:
+                            if gas is not None and (last or self.gas_delivery == "each"):
                                 slots_into(name, continua_here, cross, block, block)
                                 lines_into(name, gas, block, deliver=results[name])
                                 in_flight.append(block)

@@ -17,14 +17,16 @@ from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic       # noqa: E402
 
 formulae = ("H2O", "CO2")
 tables = [synthetic.line_table(f, 1., 5000.) for f in formulae]
-surface = synthetic.surface_level()
+levels = int(os.environ.get("LEVELS", "1"))
+surface = synthetic.standard_atmosphere(levels) if levels > 1 else synthetic.surface_level()
 level = synthetic.Atmos(p=surface.p, t=surface.t, vmr={f: surface.vmr[f] for f in formulae})
+fmt = os.environ.get("FORMAT", "total")
 grid = np.arange(1., 5000., 0.001)
 spec = Spectroscopy(level, grid, MemoryDatabase(tables))
 spec.delivery_pieces = int(os.environ.get("PIECES", "4"))
 for _ in range(6):
-    spec.compute_absorption(output_format="total")
+    spec.compute_absorption(output_format=fmt)
 time.sleep(0.05)
 start = time.perf_counter()
-spec.compute_absorption(output_format="total")
+spec.compute_absorption(output_format=fmt)
 print(f"last call: {(time.perf_counter() - start)*1e3:.2f} ms")
