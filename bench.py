@@ -736,6 +736,12 @@ def run():
     if world != args.gpus:
         args.gpus = world
 
+    # stdout carries the one JSON line and nothing else: whatever libraries write to file
+    # descriptor 1 from here on (gloo announces its connections there) goes to stderr.
+    sys.stdout.flush()
+    result_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -1181,7 +1187,7 @@ def run():
             if workers > 1:
                 line["cpu_baseline_parallel"] = cpu_baseline_parallel(
                     tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
-        print(json.dumps(line))
+        print(json.dumps(line), file=result_stream, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

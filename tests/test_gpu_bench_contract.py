@@ -18,8 +18,9 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
 def run(command, env=None):
     result = subprocess.run(command, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert result.returncode == 0, result.stderr[-3000:]
-    lines = [x for x in result.stdout.strip().splitlines() if x.startswith("{")]
-    assert len(lines) == 1, result.stdout[-2000:]
+    # stdout is the one JSON line and nothing else (library chatter goes to stderr)
+    lines = result.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), result.stdout[-2000:]
     return json.loads(lines[0])
 
 
