@@ -431,6 +431,7 @@ struct lbl_engine
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // pedestal chain by relaxation (pedestal.h), serial chain behind it
+    int relax_launches = 5;         // how many relaxation launches before the serial chain (2 ... 7)
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
@@ -1568,7 +1569,8 @@ int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_fo
             {
                 engine->timed(kTimePedestal, ped_stream, [&] {
                     pedestal_finish(lane.pedestal, ped_stream, m->view(), lane.wing.data,
-                                    lane.core.data, g, count, n_cells, engine->scan_chain != 0);
+                                    lane.core.data, g, count, n_cells, engine->scan_chain != 0,
+                                    engine->relax_launches);
                 });
                 Lane::Finish & f = lane.finish;
                 f.pieces = pieces;
@@ -2104,6 +2106,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "interp_shape" && value >= 0 && value < 100)
     {
         engine->interp_shape = (int)value;
+    }
+    else if (key == "relax_launches" && value >= 2 && value <= 7)
+    {
+        engine->relax_launches = (int)value;
     }
     else if (key == "scan_chain" && (value == 0 || value == 1))
     {

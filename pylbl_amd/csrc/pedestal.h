@@ -58,21 +58,18 @@ struct RunMeta
     int pad;
 };
 
-constexpr int kLinkWords = 4;       // history visible to a run: the previous 64 kLinkWords runs
-constexpr int kLinkReach = 64*kLinkWords;
-
 struct alignas(16) RunLink
 {
     double ks;          // GS + VS: first-slot candidate before subtracting earlier pedestals
     double ke;          // GE + VE: last-slot candidate
-    unsigned long long mask_s[kLinkWords];  // bit j of word h: run r-1-j-64h holds this run's first slot
-    unsigned long long mask_e[kLinkWords];  // ... this run's last slot
+    unsigned long long in_s;    // bit j: run r-1-j, of the same chunk of 64 runs, holds this run's first slot
+    unsigned long long in_e;    // ... this run's last slot
     int bin;            // the run's window (RunMeta::bin)
-    int next_same;      // the next run with the same bin, -1 if none
     int n_slots;
+    int begin;          // the first earlier run that can hold this run's first slot
     int first_of_bin;   // 1: no earlier run has this bin
 };
-static_assert(sizeof(RunLink) == 32 + 16*kLinkWords, "RunLink");
+static_assert(sizeof(RunLink) == 48, "RunLink");
 
 template <typename T>
 struct RawBuffer
@@ -106,7 +103,10 @@ struct PedestalWorkspace
     RawBuffer<double> slot_sums;    // [levels][max_runs][slot_stride]
     RawBuffer<RunLink> links;       // [levels][max_runs]
     RawBuffer<double> pedestals[2]; // [levels][max_runs]: the relaxation's two sets of values
-    RawBuffer<int> prefix_last;     // [levels][max_runs]
+    RawBuffer<int2> run_slots;      // [levels][max_runs]: the runs' end slots, packed for the relaxation
+    RawBuffer<int> run_bin;         // [levels][max_runs]
+    RawBuffer<int> bin_end;         // [levels][bins]: 1 + the last run of every bin
+    RawBuffer<int> prefix_bin;      // [levels][max_runs]: running maximum of the runs' bins
     RawBuffer<int> state;           // [levels][kChainState], see run_prefix_kernel
     RawBuffer<double> slots;        // [levels][cells+1]       (only when LDS is too small)
     RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]
@@ -119,7 +119,7 @@ inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cu
 {
     const long long stride = 2*cut_off + 3;
     const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2));
-    return n_lines*4 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 24) +
+    return n_lines*4 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 40) +
            4ll*(n_cells + stride)*8;
 }
 
@@ -400,23 +400,34 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
 //     P_r = min( Ks_r - sum_{q<r} P_q [fs_r in W_q] ,  Ke_r - sum_{q<r} P_q [ls_r in W_q] )
 // with fs_r / ls_r the run's end slots and Ks / Ke the profile sums on them (earlier runs' and
 // its own).  Which earlier runs hold a slot, and the G sums, do not depend on the pedestals:
-// run_links_kernel finds them in parallel (bit masks over the previous 128 runs).  What is left
-// is a triangular system in the P's -- every P_r is a fixed function of earlier ones -- and a
-// triangular system has exactly one solution, which plain iteration P <- F(P) reaches from any
-// start after as many sweeps as its longest chain of dependences that MATTER: a run whose last
-// slot is the smaller end takes its pedestal from there, and a last slot is fresh -- only the
-// run's own window, and the neighbour's where pressure shifts make two windows alternate, has
-// added to it -- so such a run does not look at history at all.  On every line table tried
-// (uniform, banded, sparse: profiles/r04_pedestal_branches.txt) that is all but a handful of
-// runs, and chains are 2-4 runs long.  run_relax_kernel: one wavefront per 64 consecutive runs
-// (lane = run), sweeps inside the chunk until nothing changes, earlier chunks' values taken from
-// the previous launch.  Three launches; the second and third report whether anything changed,
-// and a launch that changed nothing has verified a fixed point, i.e. the solution the serial
-// chain would compute with the same formula, bit for bit and independent of how it was reached.
-// Levels that have not settled by then (or whose windows reach back more than 128 runs) keep
-// run_chain_kernel.  ~25 us for the 400 k-line benchmark table, where the serial forms take a
-// wavefront 0.2-0.75 ms: one wavefront issues an instruction every fourth cycle at best, and
-// 5 300 dependent steps of ~100 instructions are 2 M cycles however they are arranged.
+// run_links_kernel sums them in parallel, one wavefront per run.  What is left is a triangular
+// system in the P's -- every P_r is a fixed function of earlier ones -- and a triangular system
+// has exactly one solution, which plain iteration P <- F(P) reaches from any start after as many
+// sweeps as its longest chain of dependences that MATTER: a run whose last slot is the smaller end
+// takes its pedestal from there, and a last slot is fresh -- only the run's own window, and the
+// neighbour's where pressure shifts make two windows alternate, has added to it -- so such a run
+// does not look at history at all.  On every line table tried (uniform, banded, sparse:
+// profiles/r04_pedestal_branches.txt) that is all but a handful of runs, and chains are 2-4 runs
+// long.  run_relax_kernel: one wavefront per 64 consecutive runs (lane = run), the chunk solved
+// exactly by forward substitution, earlier chunks' values taken from the previous launch.  The
+// second and later launches report whether anything changed, and a launch that changed nothing
+// has verified a fixed point, i.e. the solution a serial evaluation of the same formula gives, bit
+// for bit and independent of how it was reached.  Levels that have not settled after the last
+// launch keep run_chain_kernel.  ~25 us for the 400 k-line benchmark table, where the serial
+// forms take a wavefront 0.2-0.75 ms: one wavefront issues an instruction every fourth cycle at
+// best, and 5 300 dependent steps of ~100 instructions are 2 M cycles however they are arranged.
+//
+// WHICH earlier runs: a window is fixed by its bin b (RunMeta::bin) -- slots max(b - 2 cut_off - 1,
+// 0) to min(b, slot of the last grid point) -- so a slot c is held by the bins c ... c + 2 cut_off
+// + 1 and by no other.  In a table in ascending order whose pressure shifts move a line by less
+// than a wavenumber every run before r has a bin <= b_r + 1 (checked: prefix maxima of the bins;
+// the serial chain takes a level where it fails), so the prefix maxima rise with the run index and
+// the runs that can hold c begin where the prefix maximum reaches c: found by a search, then one
+// stretch of runs up to r, each tested against the slot.  However many runs that is -- 60 for the
+// benchmark's tables, 1 800 where a 4 M-line table has 800 lines to the wavenumber and dozens of
+// them alternate between two windows at every integer -- nothing is out of sight.  (The first form
+// of this kept bit masks over the previous 256 runs and gave up beyond.)  What still costs
+// launches is a chain that matters ACROSS chunks: one launch per boundary it crosses.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double read_lane(double value, int lane)
 {
@@ -426,43 +437,60 @@ __device__ __forceinline__ double read_lane(double value, int lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// (kLinkReach = 256 runs of history: a uniform 400 k-line table at 1 atm needs 63 -- one run per
-// window plus a few where shifted lines alternate between two windows -- the same lines in eight
-// Gaussian bands 177.)
+// Per level: [0] 1 while the relaxation applies (cleared by run_links_kernel where rows are too far
+// out of order or one window's runs are spread over more than kMaxStretch runs), [k] something
+// changed in relaxation launch k (k = 1 .. launches-1), [7] the number of launches queued.
+constexpr int kChainState = 8;
+constexpr int kMaxRelaxLaunches = 7;
+constexpr int kMaxStretch = 2048;
 
-// Per level: [0] 1 while the parallel chain applies (cleared by run_links_kernel where a window
-// reaches back beyond kLinkReach runs), [1] / [2] something changed in the second / third
-// relaxation launch, [3] spare.
-constexpr int kChainState = 4;
+// A launch that changed nothing has verified the values it was handed.
+__device__ __forceinline__ bool chain_verified_before(const int * state, int launch)
+{
+    for (int k = 1; k < launch; ++k)
+    {
+        if (state[k] == 0) return true;
+    }
+    return false;
+}
 
 __device__ __forceinline__ bool chain_settled(const int * state)
 {
-    return state[0] != 0 && (state[1] == 0 || state[2] == 0);
+    return state[0] != 0 && chain_verified_before(state, state[kChainState - 1]);
 }
 
-// prefix_last[r] = max over q <= r of the runs' last slots (one workgroup per level: every thread
-// takes a contiguous share of the runs, the shares' maxima are scanned, the shares written back).
-// Also resets the level's chain state.
+// prefix_bin[r] = max over q <= r of the runs' bins (one workgroup per level: every thread takes
+// a contiguous share of the runs, the shares' maxima are scanned, the shares written back);
+// bin_end[b] = 1 + the last run of bin b (preset to zero).  Also resets the level's chain state.
 __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __restrict__ run_count,
-                                                          int max_runs,
+                                                          int max_runs, int n_bins,
                                                           const RunMeta * __restrict__ runs,
-                                                          int * __restrict__ prefix_last,
-                                                          int * __restrict__ state, int start_state)
+                                                          int * __restrict__ prefix_bin,
+                                                          int * __restrict__ bin_end,
+                                                          int * __restrict__ state, int start_state,
+                                                          int launches)
 {
     __shared__ int wave_max[kScanThreads/64];
     const int level = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int count = run_count[level];
     const RunMeta * meta = runs + (long long)level*max_runs;
-    int * out = prefix_last + (long long)level*max_runs;
+    int * out = prefix_bin + (long long)level*max_runs;
+    int * end_of = bin_end + (long long)level*n_bins;
     if (threadIdx.x < kChainState)
     {
-        state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state : 0;
+        state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state
+                                                 : threadIdx.x == kChainState - 1 ? launches : 0;
     }
     const int share = (count + kScanThreads - 1)/kScanThreads;
     const int begin = min(threadIdx.x*share, count), end = min(begin + share, count);
     int mine = -1;
-    for (int r = begin; r < end; ++r) mine = max(mine, meta[r].last_slot);
+    for (int r = begin; r < end; ++r)
+    {
+        const int bin = meta[r].bin;
+        mine = max(mine, bin);
+        if (start_state != 0 && bin >= 0 && bin < n_bins) atomicMax(&end_of[bin], r + 1);
+    }
     int scan = mine;
     for (int offset = 1; offset < 64; offset <<= 1)
     {
@@ -477,20 +505,44 @@ __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __
     int running = max(before, lane > 0 ? up : -1);      // everything before this thread's share
     for (int r = begin; r < end; ++r)
     {
-        running = max(running, meta[r].last_slot);
+        running = max(running, meta[r].bin);
         out[r] = running;
     }
 }
 
-// One wavefront per run: lane j looks at run r-1-j and r-65-j -- does it hold this run's end
-// slots, and what did it add there -- and at runs r+1+j, r+65+j for the next run of the same
-// bin (the bins' totals are summed along those links, in row order).
+// First index in [lo, hi) whose value is >= x in a non-decreasing array, found by a whole
+// wavefront: 64 probes per step.
+__device__ inline int wave_lower_bound(const int * __restrict__ values, int lo, int hi, int x)
+{
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 64)
+    {
+        const int stride = (hi - lo + 63) >> 6;
+        const int at = lo + lane*stride;
+        const bool below = at < hi && values[at] < x;
+        const int count = __builtin_popcountll(__ballot(below));
+        if (count == 0) return lo;
+        const int base = lo + (count - 1)*stride;
+        hi = min(base + stride, hi);
+        lo = base + 1;
+    }
+    const int at = lo + lane;
+    const bool below = at < hi && values[at] < x;
+    return lo + __builtin_popcountll(__ballot(below));
+}
+
+// One wavefront per run: the stretch of earlier runs that can hold its first slot (from where
+// the prefix maximum of the bins reaches that slot), what they added on its end slots, which runs
+// of its own chunk of 64 hold them, and whether it is the first run of its bin.
 __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ run_count,
-                                                       int max_runs, int slot_stride,
+                                                       int max_runs, int slot_stride, int n_bins,
                                                        const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
-                                                       const int * __restrict__ prefix_last,
+                                                       const int * __restrict__ prefix_bin,
+                                                       const int * __restrict__ bin_end,
                                                        RunLink * __restrict__ links,
+                                                       int2 * __restrict__ run_slots,
+                                                       int * __restrict__ run_bin,
                                                        int * __restrict__ state)
 {
     const int level = blockIdx.y;
@@ -498,59 +550,69 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
     const int count = run_count[level];
     const RunMeta * meta = runs + (long long)level*max_runs;
     const double * sums = slot_sums + (long long)level*max_runs*slot_stride;
+    const int * prefix = prefix_bin + (long long)level*max_runs;
     for (int r = blockIdx.x; r < count; r += gridDim.x)
     {
         const RunMeta m = meta[r];
-        // Nothing older than the visible history may hold one of this run's end slots.
-        if (lane == 0 && r > kLinkReach &&
-            prefix_last[(long long)level*max_runs + r - kLinkReach - 1] >= m.first_slot)
-        {
-            atomicAnd(&state[level*kChainState], 0);
-        }
-        RunLink link;
+        const bool bin_ok = m.bin >= 0 && m.bin < n_bins;
+        // (the slots' bins: a run holds slot c exactly if its bin lies in c ... c + 2 cut_off + 1,
+        // so the earliest holder of the first slot is the first run whose prefix maximum is >= it)
+        const int begin = wave_lower_bound(prefix, 0, r, m.first_slot);
         double gs = 0., ge = 0.;
         bool seen_before = false;
-        for (int half = 0; half < kLinkWords; ++half)
+        for (int q0 = begin; q0 < r; q0 += 64)
         {
-            const int q = r - 1 - half*64 - lane;
-            bool holds_s = false, holds_e = false;
-            double at_s = 0., at_e = 0.;
-            if (q >= 0)
+            const int q = q0 + lane;
+            if (q < r)
             {
                 const RunMeta e = meta[q];
-                holds_s = e.first_slot <= m.first_slot && m.first_slot <= e.last_slot;
-                holds_e = e.first_slot <= m.last_slot && m.last_slot <= e.last_slot;
-                if (holds_s) at_s = sums[(long long)q*slot_stride + (m.first_slot - e.first_slot)];
-                if (holds_e) at_e = sums[(long long)q*slot_stride + (m.last_slot - e.first_slot)];
+                if (e.first_slot <= m.first_slot && m.first_slot <= e.last_slot)
+                {
+                    gs += sums[(long long)q*slot_stride + (m.first_slot - e.first_slot)];
+                }
+                if (e.first_slot <= m.last_slot && m.last_slot <= e.last_slot)
+                {
+                    ge += sums[(long long)q*slot_stride + (m.last_slot - e.first_slot)];
+                }
                 seen_before = seen_before || e.bin == m.bin;
             }
-            link.mask_s[half] = __ballot(holds_s);
-            link.mask_e[half] = __ballot(holds_e);
-            gs += at_s;
-            ge += at_e;
         }
         for (int offset = 32; offset > 0; offset >>= 1)
         {
             gs += __shfl_xor(gs, offset, 64);
             ge += __shfl_xor(ge, offset, 64);
         }
-        int next = -1;
-        for (int half = 0; half < kLinkWords && next < 0; ++half)
+        // The runs of the same chunk of 64: bit j is run r-1-j.
+        const int q = r - 1 - lane;
+        bool holds_s = false, holds_e = false;
+        if (q >= (r & ~63))
         {
-            const int q = r + 1 + half*64 + lane;
-            const unsigned long long same = __ballot(q < count && meta[min(q, count - 1)].bin == m.bin);
-            if (same != 0ull) next = r + 1 + half*64 + __builtin_ctzll(same);
+            const RunMeta e = meta[q];
+            holds_s = e.first_slot <= m.first_slot && m.first_slot <= e.last_slot;
+            holds_e = e.first_slot <= m.last_slot && m.last_slot <= e.last_slot;
         }
+        const unsigned long long in_s = __ballot(holds_s), in_e = __ballot(holds_e);
         const bool first_of_bin = __ballot(seen_before) == 0ull;
         if (lane == 0)
         {
+            // Rows too far out of order for the stretch to be what it is taken for; or a window
+            // whose runs are spread so far that its total would be one lane's walk of thousands.
+            const bool displaced = !bin_ok || (r > 0 && prefix[r - 1] > m.bin + 1);
+            const bool spread = bin_ok && first_of_bin &&
+                                bin_end[(long long)level*n_bins + m.bin] - r > kMaxStretch;
+            if (displaced || spread) atomicAnd(&state[level*kChainState], 0);
+            RunLink link;
             link.ks = gs + m.vs;
             link.ke = ge + m.ve;
+            link.in_s = in_s;
+            link.in_e = in_e;
             link.bin = m.bin;
-            link.next_same = next;
             link.n_slots = m.n_slots;
+            link.begin = begin;
             link.first_of_bin = first_of_bin ? 1 : 0;
             links[(long long)level*max_runs + r] = link;
+            run_slots[(long long)level*max_runs + r] = make_int2(m.first_slot, m.last_slot);
+            run_bin[(long long)level*max_runs + r] = m.bin;
         }
     }
 }
@@ -561,80 +623,82 @@ __device__ __forceinline__ double run_pedestal(double k_s, double k_e, int n_slo
     return (n_slots == 1 || !(k_s - k_e > 0.)) ? k_s : k_e;
 }
 
+constexpr int kHistoryTile = 256;   // earlier runs staged in LDS at a time
+
 // One wavefront per 64 consecutive runs (lane = run).  Inside the chunk the system is solved
 // exactly, run by run (forward substitution: run t's value is broadcast, the later lanes whose
 // masks name it add it to their sums -- ~20 instructions a step); what earlier chunks hold comes
-// from the previous launch (step 0: zero).  So launch k is exact for every chain of dependences
-// that crosses at most k chunk boundaries, whatever its length inside a chunk (the runs of the
+// from the previous launch (launch 0: zero): the stretch of runs from the first that can hold a
+// slot of this chunk up to the chunk, staged through LDS, oldest first, every lane testing the run
+// against its own two end slots.  So launch k is exact for every chain of dependences that
+// crosses at most k chunk boundaries, whatever its length inside a chunk (the runs of the
 // 2 cut_off + 2 windows clipped at either end of the grid form such chains: each holds the end
-// slot of all the others).  Steps 1 and 2 report a change and sum the bins' totals from the
+// slot of all the others).  Launches >= 1 report a change and sum the bins' totals from the
 // values they were handed -- final if the launch changes nothing anywhere.
 __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ run_count,
-                                                       int max_runs, int n_bins, int step,
+                                                       int max_runs, int n_bins, int launch,
                                                        const RunLink * __restrict__ links,
+                                                       const int2 * __restrict__ run_slots,
+                                                       const int * __restrict__ run_bin,
+                                                       const int * __restrict__ bin_end,
                                                        const double * __restrict__ p_in,
                                                        double * __restrict__ p_out,
                                                        int * __restrict__ state,
                                                        double * __restrict__ bin_sum)
 {
-    __shared__ double history[kLinkReach];      // P of runs base-256 ... base-1 (previous launch)
+    __shared__ double history_p[kHistoryTile];
+    __shared__ int2 history_slots[kHistoryTile];
     const int level = blockIdx.y;
     const int lane = threadIdx.x;
     const int count = run_count[level];
     const int base = blockIdx.x*64;
     int * flags = state + level*kChainState;
     if (base >= count || flags[0] == 0) return;
-    if (step == 2 && flags[1] == 0) return;         // the second launch verified the first
-    const RunLink * link = links + (long long)level*max_runs;
+    if (chain_verified_before(flags, launch)) return;       // an earlier launch changed nothing
     const double * from = p_in + (long long)level*max_runs;
+    const int2 * slots_of = run_slots + (long long)level*max_runs;
     const int r = base + lane;
     const bool valid = r < count;
     RunLink mine;
     mine.ks = mine.ke = 0.;
-    for (int h = 0; h < kLinkWords; ++h) mine.mask_s[h] = mine.mask_e[h] = 0ull;
-    mine.bin = -1; mine.next_same = -1; mine.n_slots = 0; mine.first_of_bin = 0;
-    if (valid) mine = link[r];
-    static_assert(kLinkWords == 4, "the word of a bit is chosen by comparisons below");
-    const unsigned long long mask_s0 = mine.mask_s[0], mask_s1 = mine.mask_s[1];
-    const unsigned long long mask_s2 = mine.mask_s[2], mask_s3 = mine.mask_s[3];
-    const unsigned long long mask_e0 = mine.mask_e[0], mask_e1 = mine.mask_e[1];
-    const unsigned long long mask_e2 = mine.mask_e[2], mask_e3 = mine.mask_e[3];
-    double given = 0.;
-    // Sums over the runs of earlier chunks: bit j of a mask is run r-1-j, history entry t is run
-    // base-256+t, so entry t is bit lane+255-t.  Oldest first; entries no lane names are skipped.
-    double before_s = 0., before_e = 0.;
-    if (step > 0 && base > 0)
+    mine.in_s = mine.in_e = 0ull;
+    mine.bin = -1; mine.n_slots = 0; mine.begin = base; mine.first_of_bin = 0;
+    int2 ends = make_int2(-1, -1);
+    if (valid)
     {
-        for (int h = 0; h < kLinkWords; ++h)
-        {
-            const int q = base - kLinkReach + 64*h + lane;
-            history[64*h + lane] = q >= 0 ? from[q] : 0.;
-        }
-        __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
-        const unsigned long long any3 = mask_s3 | mask_e3, any2 = mask_s2 | mask_e2;
-        const unsigned long long any1 = mask_s1 | mask_e1, any0 = mask_s0 | mask_e0;
-        const int top_bit = any3 ? 255 - __builtin_clzll(any3) : any2 ? 191 - __builtin_clzll(any2)
-                            : any1 ? 127 - __builtin_clzll(any1) : any0 ? 63 - __builtin_clzll(any0) : -1;
-        int oldest = top_bit >= lane ? lane + kLinkReach - 1 - top_bit : kLinkReach;
+        mine = links[(long long)level*max_runs + r];
+        ends = slots_of[r];
+    }
+    double given = 0., before_s = 0., before_e = 0.;
+    if (launch > 0 && valid) given = from[r];
+    if (launch > 0 && base > 0)
+    {
+        // The earliest run any lane of the chunk looks back to.
+        int oldest = min(mine.begin, base);
         for (int offset = 32; offset > 0; offset >>= 1)
         {
             oldest = min(oldest, __shfl_xor(oldest, offset, 64));
         }
-        for (int t = max(oldest, 0); t < kLinkReach; ++t)
+        for (int tile = oldest; tile < base; tile += kHistoryTile)
         {
-            const double value = history[t];
-            const int j = lane + kLinkReach - 1 - t;    // lane <= j: the runs of earlier chunks
-            const unsigned long long word_s = j < 128 ? (j < 64 ? mask_s0 : mask_s1)
-                                                      : (j < 192 ? mask_s2 : mask_s3);
-            const unsigned long long word_e = j < 128 ? (j < 64 ? mask_e0 : mask_e1)
-                                                      : (j < 192 ? mask_e2 : mask_e3);
-            const int shift = j & 63;
-            if (j < kLinkReach && ((word_s >> shift) & 1ull)) before_s += value;
-            if (j < kLinkReach && ((word_e >> shift) & 1ull)) before_e += value;
+            const int length = min(kHistoryTile, base - tile);
+            __builtin_amdgcn_wave_barrier();        // the previous tile has been read
+            for (int t = lane; t < length; t += 64)
+            {
+                history_p[t] = from[tile + t];
+                history_slots[t] = slots_of[tile + t];
+            }
+            __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
+            for (int t = 0; t < length; ++t)
+            {
+                const double value = history_p[t];
+                const int2 window = history_slots[t];
+                if (window.x <= ends.x && ends.x <= window.y) before_s += value;
+                if (window.x <= ends.y && ends.y <= window.y) before_e += value;
+            }
         }
     }
-    if (step > 0 && valid) given = from[r];
-    // The chunk itself: run t of the chunk is bit lane-1-t of the later lanes' first words.
+    // The chunk itself: run t of the chunk is bit lane-1-t of the later lanes' masks.
     double p = 0.;
     const int last = min(64, count - base);
     for (int t = 0; t < last; ++t)
@@ -645,22 +709,28 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
         const int j = lane - 1 - t;
         if (j >= 0)
         {
-            if ((mask_s0 >> j) & 1ull) before_s += settled;
-            if ((mask_e0 >> j) & 1ull) before_e += settled;
+            if ((mine.in_s >> j) & 1ull) before_s += settled;
+            if ((mine.in_e >> j) & 1ull) before_e += settled;
         }
     }
     if (valid) p_out[(long long)level*max_runs + r] = p;
-    if (step > 0)
+    if (launch > 0)
     {
         const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
         if (__ballot(moved) != 0ull && lane == 0)
         {
-            atomicOr(&flags[step], 1);      // (run_prefix_kernel cleared the flags)
+            atomicOr(&flags[launch], 1);        // (run_prefix_kernel cleared the flags)
         }
         if (valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins)
         {
+            // The bin's total of the values handed in: its runs in row order, up to its last.
+            const int * bins = run_bin + (long long)level*max_runs;
+            const int end = bin_end[(long long)level*n_bins + mine.bin];
             double total = 0.;
-            for (int q = r; q >= 0; q = link[q].next_same) total += from[q];
+            for (int q = r; q < end; ++q)
+            {
+                if (bins[q] == mine.bin) total += from[q];
+            }
             bin_sum[(long long)level*n_bins + mine.bin] = total;
         }
     }
@@ -993,13 +1063,15 @@ inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const
 // chain alone.
 inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                             const LineWing * wing, const LineCore * core, const GridSpec & g,
-                            int count, int n_cells, bool parallel_chain = true)
+                            int count, int n_cells, bool parallel_chain = true, int relax_launches = 5)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
     const int slot_stride = 2*g.cut_off + 3;
     const int n_bins = n_cells + 2*g.cut_off + 3;
+    relax_launches = std::min(std::max(relax_launches, 2), kMaxRelaxLaunches);
     ws.bin_sum.reserve((size_t)count*n_bins);
+    ws.bin_end.reserve((size_t)count*n_bins);
     ws.cell_sum.reserve((size_t)count*n_cells);
     ws.point_sum.reserve((size_t)count*n_cells);
     ws.state.reserve((size_t)count*kChainState);
@@ -1008,6 +1080,8 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         // Bins without a run keep this zero (the relaxation only writes the bins it has runs for).
         check(hipMemsetAsync(ws.bin_sum.data, 0, (size_t)count*n_bins*sizeof(double), stream),
               "bin sums");
+        check(hipMemsetAsync(ws.bin_end.data, 0, (size_t)count*n_bins*sizeof(int), stream),
+              "bin ends");
     }
     // (Sizing the pass by a host-side bound on the runs instead -- no wait here -- was built twice,
     // rounds 3 and 4: the user-facing call gains 1 % at most, calls queued in numbers lose the
@@ -1025,30 +1099,34 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
                        ws.run_start.data, ws.run_count.data, max_runs, slot_stride,
                        ws.runs.data, ws.slot_sums.data);
     check(hipGetLastError(), "run_sums_kernel");
-    ws.prefix_last.reserve((size_t)count*max_runs);
+    ws.prefix_bin.reserve((size_t)count*max_runs);
     hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
-                       ws.run_count.data, max_runs, ws.runs.data, ws.prefix_last.data,
-                       ws.state.data, parallel_chain ? 1 : 0);
+                       ws.run_count.data, max_runs, n_bins, ws.runs.data, ws.prefix_bin.data,
+                       ws.bin_end.data, ws.state.data, parallel_chain ? 1 : 0, relax_launches);
     if (parallel_chain)
     {
         ws.links.reserve((size_t)count*max_runs);
+        ws.run_slots.reserve((size_t)count*max_runs);
+        ws.run_bin.reserve((size_t)count*max_runs);
         ws.pedestals[0].reserve((size_t)count*max_runs);
         ws.pedestals[1].reserve((size_t)count*max_runs);
         hipLaunchKernelGGL(run_links_kernel, dim3(std::min(max_runs, 65535), count), dim3(64), 0,
-                           stream, ws.run_count.data, max_runs, slot_stride, ws.runs.data,
-                           ws.slot_sums.data, ws.prefix_last.data, ws.links.data, ws.state.data);
+                           stream, ws.run_count.data, max_runs, slot_stride, n_bins, ws.runs.data,
+                           ws.slot_sums.data, ws.prefix_bin.data, ws.bin_end.data, ws.links.data,
+                           ws.run_slots.data, ws.run_bin.data, ws.state.data);
         const dim3 chunks((max_runs + 63)/64, count);
-        for (int step = 0; step < 3; ++step)
+        for (int launch = 0; launch < relax_launches; ++launch)
         {
             hipLaunchKernelGGL(run_relax_kernel, chunks, dim3(64), 0, stream, ws.run_count.data,
-                               max_runs, n_bins, step, ws.links.data,
-                               ws.pedestals[(step + 1) & 1].data, ws.pedestals[step & 1].data,
+                               max_runs, n_bins, launch, ws.links.data, ws.run_slots.data,
+                               ws.run_bin.data, ws.bin_end.data,
+                               ws.pedestals[(launch + 1) & 1].data, ws.pedestals[launch & 1].data,
                                ws.state.data, ws.bin_sum.data);
         }
         check(hipGetLastError(), "run_relax_kernel");
     }
-    // The serial chain takes the levels the relaxation left (windows that reach back more than
-    // kLinkReach runs: rows far out of order; or not settled after three launches).  Behind the
+    // The serial chain takes the levels the relaxation left (rows far out of order; or not settled
+    // after the last launch: chains of dependences across many chunks of runs).  Behind the
     // relaxation it is launched in its small-LDS form (slots of the spectrum in HBM, the active
     // ones in registers): it usually only looks at the flags and returns, and must not queue for
     // most of a CU's LDS to do that (the accumulate workgroups beside it hold 12-27 KB each).

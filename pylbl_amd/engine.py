@@ -6,6 +6,7 @@ library is missing or no MI355X is visible, creating an Engine raises.
 """
 from ctypes import CDLL, POINTER, Structure, byref, c_char_p, c_double, c_int32, c_int64, \
                    c_void_p
+import os
 from pathlib import Path
 import threading
 import weakref
@@ -326,6 +327,10 @@ class Engine(object):
         # one block in a fixed order, one deferred call per engine).  Single calls need no lock:
         # the C ABI serialises them per handle (include/lbl_amd.h, "Threads").
         self.pipeline = threading.RLock()
+        # Options for every engine of the process, for experiments: PYLBL_AMD_OPTIONS="name=value,..."
+        for pair in filter(None, os.environ.get("PYLBL_AMD_OPTIONS", "").split(",")):
+            name, _, value = pair.partition("=")
+            self.set_option(name.strip(), float(value))
 
     def host_array(self, shape):
         """float64 array of the given shape in page-locked host memory (recycled, see

@@ -1,21 +1,42 @@
-"""Pedestal pass time with the parallel chain (relaxation) on/off for uniform and banded tables (one process)."""
-import sys, time
+"""Pedestal pass time with the relaxation (scan_chain 1) and with the serial chain alone (0) for uniform,
+banded and very dense tables (one process).  LAUNCHES=n: relaxation launches (default 5)."""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from pylbl_amd import synthetic
 from pylbl_amd.engine import DeviceSpectra, Engine
 e = Engine(0)
 e.set_option("farfield", 1)
+e.set_option("relax_launches", int(os.environ.get("LAUNCHES", "5")))
 v0, vn, npv = 1, 5001, 1000
 out = DeviceSpectra(e, 1, (vn - v0)*npv)
 tables = {"uniform 400k": synthetic.line_table("CO2", 1., 5000.),
           "banded 400k": synthetic.banded_line_table("CO2", 1., 5000., num_lines=400_000, bands=8, seed=4),
           "banded 1.6M": synthetic.banded_line_table("CO2", 1., 5000., num_lines=1_600_000, bands=8, seed=5)}
+
+
+def dense_interior(num_lines, seed):
+    """Eight Gaussian bands well inside the grid (no lines clipped onto its ends, which
+    banded_line_table piles up at v_hi): what is dense here is dense the way a band centre is."""
+    table = synthetic.line_table("CO2", 1., 5000., num_lines, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    centres = rng.uniform(600., 4400., 8)
+    widths = rng.uniform(15., 80., 8)
+    which = rng.integers(0, 8, table.num_lines)
+    nu = rng.normal(centres[which], widths[which])
+    nu = nu[(nu > 1.) & (nu < 5000.)]
+    table = table.subset(np.arange(table.num_lines) < nu.size)
+    table.nu = np.sort(nu)
+    return table
+
+
+tables["interior 1.6M"] = dense_interior(1_600_000, 5)
+tables["interior 4M"] = dense_interior(4_000_000, 6)
 for name, table in tables.items():
     h = e.load(table)
     for scan in (1, 0):
         e.set_option("scan_chain", scan)
-        for ped in (False, True):
+        for ped in ((False, True) if scan == 1 else (True,)):
             e.compute(h, 288.99, 98388., 3.6e-4, v0, vn, npv, out=out, remove_pedestal=ped)
             e.synchronize()
             t0 = time.perf_counter()

@@ -426,6 +426,55 @@ def test_pedestal_chain_variants_agree(engine, oracle):
     engine.free(molecule)
 
 
+def test_pedestal_relaxation_on_a_very_dense_table(engine, oracle):
+    """Dozens of shifted lines alternating between two windows at EVERY integer wavenumber: a run's
+    first slot is held by ~1 500 earlier runs (the relaxation's first form saw 256 back and left
+    such a level to the serial chain; it now walks the whole stretch, pedestal.h).  Relaxation and
+    serial chain agree far below the bar, both meet it against the oracle -- also with two
+    launches only, where the serial chain behind them takes whatever has not settled."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("CO2", 2290., 2400., num_lines=30000, seed=96,
+                                 tips_range=(150, 400))
+    rng = np.random.default_rng(4)
+    near = rng.choice(table.num_lines, 10000, replace=False)
+    table.nu[near] = np.round(table.nu[near]) + rng.uniform(-0.004, 0.004, near.size)
+    table = table.subset(np.argsort(table.nu, kind="stable"))
+    atmos = synthetic.standard_atmosphere(3)
+    molecule = engine.load(table)
+    v0, vn, npv = 2300, 2380, 20
+    shifted = np.floor(table.nu + atmos.p[0]*9.86923e-6*table.delta_air)
+    assert np.count_nonzero(np.diff(shifted)) > 2500        # thousands of runs on 110 windows
+    try:
+        results = {}
+        for name, (scan, launches) in {"relaxation": (1, 5), "two launches": (1, 2),
+                                       "serial": (0, 5)}.items():
+            engine.set_option("scan_chain", scan)
+            engine.set_option("relax_launches", launches)
+            results[name] = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn,
+                                           npv, remove_pedestal=True)
+        engine.set_option("scan_chain", 1)
+        engine.set_option("relax_launches", 5)
+        plain = engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv)
+        scale = np.maximum(plain, 1e-300)
+        for name in ("relaxation", "two launches"):
+            assert np.max(np.abs(results[name] - results["serial"])/scale) < 1.e-7, name
+        case = golden_io.Case("dense", 0, 0, 0, 0, v0, vn, npv, 25, True, None, 0)
+        for level in (0, 2):
+            k_ref, _ = oracle.absorption_port(table, atmos.t[level], atmos.p[level],
+                                              atmos.vmr["CO2"][level], v0, vn, npv,
+                                              remove_pedestal=True)
+            for name in results:
+                assert_spectrum(results[name][level], k_ref, case, f"{name} level {level}",
+                                plain[level],
+                                conditioning=lambda: oracle_conditioning(
+                                    oracle, table, atmos.t[level], atmos.p[level],
+                                    atmos.vmr["CO2"][level], v0, vn, npv, 25, k_ref))
+    finally:
+        engine.set_option("scan_chain", 1)
+        engine.set_option("relax_launches", 5)
+    engine.free(molecule)
+
+
 def test_empty_and_degenerate_inputs(engine, oracle):
     """Empty table, a table with no line in reach of the grid, a single line, a one-cell grid,
     a cut-off wider than the grid."""
