@@ -24,9 +24,9 @@
 //
 // Kernels: run_count / run_offset / run_compact (find runs in reference row order: a
 // three-pass parallel scan), run_sums (one wavefront per run: profile values on the run's
-// slots, in parallel over runs), run_prefix / run_links (which earlier runs hold a run's end
-// slots, and what they added there), run_relax (the recurrence in the runs' pedestal totals as
-// a triangular system: three launches, each exact inside chunks of 64 runs), run_chain (one
+// slots, in parallel over runs), run_prefix / run_links (the stretch of earlier runs that can
+// hold a run's end slots, and what they added there), run_relax (the recurrence in the runs'
+// pedestal totals as a triangular system: a few launches, each exact inside chunks of 64 runs), run_chain (one
 // wavefront per level: the serial form, for the levels the relaxation leaves),
 // pedestal_tables (per 1 cm-1 cell: total pedestal covering its interior / integer point).
 #pragma once
