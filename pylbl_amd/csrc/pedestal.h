@@ -438,7 +438,8 @@ __device__ __forceinline__ double read_lane(double value, int lane)
 }
 
 // Per level: [0] 1 while the relaxation applies (cleared by run_links_kernel where rows are too far
-// out of order or one window's runs are spread over more than kMaxStretch runs), [k] something
+// out of order, by the first relaxation launch where one window's runs are spread over more than
+// kMaxStretch runs: its total would be one lane's walk of thousands), [k] something
 // changed in relaxation launch k (k = 1 .. launches-1), [7] the number of launches queued.
 constexpr int kChainState = 8;
 constexpr int kMaxRelaxLaunches = 7;
@@ -460,13 +461,15 @@ __device__ __forceinline__ bool chain_settled(const int * state)
 }
 
 // prefix_bin[r] = max over q <= r of the runs' bins (one workgroup per level: every thread takes
-// a contiguous share of the runs, the shares' maxima are scanned, the shares written back);
-// bin_end[b] = 1 + the last run of bin b (preset to zero).  Also resets the level's chain state.
+// a contiguous share of the runs, the shares' maxima are scanned, the shares written back).
+// Also resets the level's chain state and clears what the relaxation fills: bin_end (1 + the
+// last run of every bin, run_links_kernel) and bin_sum (bins without a run keep zero).
 __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __restrict__ run_count,
                                                           int max_runs, int n_bins,
                                                           const RunMeta * __restrict__ runs,
                                                           int * __restrict__ prefix_bin,
                                                           int * __restrict__ bin_end,
+                                                          double * __restrict__ bin_sum,
                                                           int * __restrict__ state, int start_state,
                                                           int launches)
 {
@@ -476,7 +479,14 @@ __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __
     const int count = run_count[level];
     const RunMeta * meta = runs + (long long)level*max_runs;
     int * out = prefix_bin + (long long)level*max_runs;
-    int * end_of = bin_end + (long long)level*n_bins;
+    if (start_state != 0)
+    {
+        for (int b = threadIdx.x; b < n_bins; b += kScanThreads)
+        {
+            bin_end[(long long)level*n_bins + b] = 0;
+            bin_sum[(long long)level*n_bins + b] = 0.;
+        }
+    }
     if (threadIdx.x < kChainState)
     {
         state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state
@@ -485,12 +495,7 @@ __global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __
     const int share = (count + kScanThreads - 1)/kScanThreads;
     const int begin = min(threadIdx.x*share, count), end = min(begin + share, count);
     int mine = -1;
-    for (int r = begin; r < end; ++r)
-    {
-        const int bin = meta[r].bin;
-        mine = max(mine, bin);
-        if (start_state != 0 && bin >= 0 && bin < n_bins) atomicMax(&end_of[bin], r + 1);
-    }
+    for (int r = begin; r < end; ++r) mine = max(mine, meta[r].bin);
     int scan = mine;
     for (int offset = 1; offset < 64; offset <<= 1)
     {
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
                                                        const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
                                                        const int * __restrict__ prefix_bin,
-                                                       const int * __restrict__ bin_end,
+                                                       int * __restrict__ bin_end,
                                                        RunLink * __restrict__ links,
                                                        int2 * __restrict__ run_slots,
                                                        int * __restrict__ run_bin,
@@ -595,12 +600,10 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
         const bool first_of_bin = __ballot(seen_before) == 0ull;
         if (lane == 0)
         {
-            // Rows too far out of order for the stretch to be what it is taken for; or a window
-            // whose runs are spread so far that its total would be one lane's walk of thousands.
+            // Rows too far out of order for the stretch to be what it is taken for.
             const bool displaced = !bin_ok || (r > 0 && prefix[r - 1] > m.bin + 1);
-            const bool spread = bin_ok && first_of_bin &&
-                                bin_end[(long long)level*n_bins + m.bin] - r > kMaxStretch;
-            if (displaced || spread) atomicAnd(&state[level*kChainState], 0);
+            if (displaced) atomicAnd(&state[level*kChainState], 0);
+            if (bin_ok) atomicMax(&bin_end[(long long)level*n_bins + m.bin], r + 1);
             RunLink link;
             link.ks = gs + m.vs;
             link.ke = ge + m.ve;
@@ -714,6 +717,11 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
         }
     }
     if (valid) p_out[(long long)level*max_runs + r] = p;
+    if (launch == 0 && valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins &&
+        bin_end[(long long)level*n_bins + mine.bin] - r > kMaxStretch)
+    {
+        atomicAnd(&flags[0], 0);
+    }
     if (launch > 0)
     {
         const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
@@ -1075,14 +1083,6 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     ws.cell_sum.reserve((size_t)count*n_cells);
     ws.point_sum.reserve((size_t)count*n_cells);
     ws.state.reserve((size_t)count*kChainState);
-    if (parallel_chain)
-    {
-        // Bins without a run keep this zero (the relaxation only writes the bins it has runs for).
-        check(hipMemsetAsync(ws.bin_sum.data, 0, (size_t)count*n_bins*sizeof(double), stream),
-              "bin sums");
-        check(hipMemsetAsync(ws.bin_end.data, 0, (size_t)count*n_bins*sizeof(int), stream),
-              "bin ends");
-    }
     // (Sizing the pass by a host-side bound on the runs instead -- no wait here -- was built twice,
     // rounds 3 and 4: the user-facing call gains 1 % at most, calls queued in numbers lose the
     // pacing this wait gives them: profiles/r03_ab_prepass.txt, r04_ab_total_order.txt.  Reading the
@@ -1102,7 +1102,8 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     ws.prefix_bin.reserve((size_t)count*max_runs);
     hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
                        ws.run_count.data, max_runs, n_bins, ws.runs.data, ws.prefix_bin.data,
-                       ws.bin_end.data, ws.state.data, parallel_chain ? 1 : 0, relax_launches);
+                       ws.bin_end.data, ws.bin_sum.data, ws.state.data, parallel_chain ? 1 : 0,
+                       relax_launches);
     if (parallel_chain)
     {
         ws.links.reserve((size_t)count*max_runs);
