@@ -444,6 +444,7 @@ __device__ __forceinline__ double read_lane(double value, int lane)
 constexpr int kChainState = 8;
 constexpr int kMaxRelaxLaunches = 7;
 constexpr int kMaxStretch = 2048;
+constexpr int kMaxHistory = 16384;  // earlier runs a run may have to look at (a 4 M-line table: 1 800)
 
 // A launch that changed nothing has verified the values it was handed.
 __device__ __forceinline__ bool chain_verified_before(const int * state, int launch)
@@ -563,9 +564,13 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
         // (the slots' bins: a run holds slot c exactly if its bin lies in c ... c + 2 cut_off + 1,
         // so the earliest holder of the first slot is the first run whose prefix maximum is >= it)
         const int begin = wave_lower_bound(prefix, 0, r, m.first_slot);
+        // (rows in no order at all: every row its own run and every stretch the whole table --
+        // such a level is the serial chain's, and nobody walks its stretches)
+        const bool too_long = r - begin > kMaxHistory;
+        const bool given_up = __builtin_amdgcn_readfirstlane(state[level*kChainState]) == 0;
         double gs = 0., ge = 0.;
         bool seen_before = false;
-        for (int q0 = begin; q0 < r; q0 += 64)
+        for (int q0 = (too_long || given_up) ? r : begin; q0 < r; q0 += 64)
         {
             const int q = q0 + lane;
             if (q < r)
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
         {
             // Rows too far out of order for the stretch to be what it is taken for.
             const bool displaced = !bin_ok || (r > 0 && prefix[r - 1] > m.bin + 1);
-            if (displaced) atomicAnd(&state[level*kChainState], 0);
+            if (displaced || too_long) atomicAnd(&state[level*kChainState], 0);
             if (bin_ok) atomicMax(&bin_end[(long long)level*n_bins + m.bin], r + 1);
             RunLink link;
             link.ks = gs + m.vs;
