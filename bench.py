@@ -22,6 +22,7 @@ Besides the contract's keys the line carries (N = 1): `roofline` (the resource t
 dominant kernel: the fp64 vector ALU), `roofline_hbm_algorithmic` (SURVEY 8d's 24 B/eval figure,
 for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure what users run:
 `sustained`, `pedestal_option`, `standard_atmosphere_option`, `banded_table_option`,
+`dense_table_option`,
 `small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`.
 """
 import argparse
@@ -81,7 +82,7 @@ def parse():
                         help="only the timed steps (what scripts/profile_bench.sh profiles)")
     parser.add_argument("--extras", default="all",
                         help="comma list of untimed legs: all, none, or any of sustained, "
-                             "pedestal, atmosphere, banded, small, farfield, api, continuum")
+                             "pedestal, atmosphere, banded, dense, small, farfield, api, continuum")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; never the headline value)")
@@ -1124,6 +1125,26 @@ def run():
                 label="same line counts clustered in 8 Gaussian bands per molecule "
                       "(synthetic.banded_line_table), remove_pedestal=True")
             for h in banded_handles:
+                engine.free(h)
+        if leg("dense") and args.config == "target":
+            # A table several times denser than the workload's (dozens of pressure-shifted lines
+            # alternate between two windows at every integer wavenumber): the step with and
+            # without the pedestal, whose chain such tables used to send to its serial form.
+            dense = [synthetic.banded_line_table("CO2", v_lo, v_hi, num_lines=1_600_000, bands=8,
+                                                 seed=5, inside=True)]
+            dense_handles = [engine.load(t) for t in dense]
+            dense_vmr = {"CO2": atmos.vmr["CO2"][:1]} if "CO2" in atmos.vmr else \
+                {"CO2": np.asarray([3.6e-4])}
+            plain = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
+                              max(args.steps//2, 2), remove_pedestal=False, ring=2,
+                              label="one molecule, 1.6 M lines in 8 Gaussian bands inside the grid "
+                                    "(synthetic.banded_line_table(inside=True))")
+            with_pedestal = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
+                                      max(args.steps//2, 2), remove_pedestal=True, ring=2,
+                                      label="the same with remove_pedestal=True")
+            line["dense_table_option"] = {"plain": plain, "remove_pedestal": with_pedestal,
+                                          "lines": int(dense[0].num_lines)}
+            for h in dense_handles:
                 engine.free(h)
         if leg("small") and args.config == "target":
             small = {}

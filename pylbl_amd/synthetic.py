@@ -81,15 +81,27 @@ def line_table(formula, v_lo=1., v_hi=5000., num_lines=None, scale=1., seed=None
         tips_temperature=temperature, tips_data=data)
 
 
-def banded_line_table(formula, v_lo=1., v_hi=5000., num_lines=100_000, bands=6, seed=None):
+def banded_line_table(formula, v_lo=1., v_hi=5000., num_lines=100_000, bands=6, seed=None,
+                      inside=False):
     """Like line_table but with line centres clustered in Gaussian bands, the way real
-    vibration-rotation bands cluster; exercises load balance of the tile schedule."""
+    vibration-rotation bands cluster; exercises load balance of the tile schedule.
+
+    Lines that fall outside [v_lo, v_hi) are moved onto its ends (thousands of them on one
+    wavenumber where a band sits near an end: a stress of its own for the pedestal chain).
+    inside=True keeps the band centres 600 cm-1 away from the ends and drops such lines instead:
+    dense the way a band centre is dense, and nothing else."""
     table = line_table(formula, v_lo, v_hi, num_lines, seed=seed)
     rng = np.random.default_rng((seed or 0) + 77)
-    centres = rng.uniform(v_lo + 100., v_hi - 100., bands)
+    margin = 600. if inside else 100.
+    centres = rng.uniform(v_lo + margin, v_hi - margin, bands)
     widths = rng.uniform(15., 80., bands)
     which = rng.integers(0, bands, table.num_lines)
-    nu = np.clip(rng.normal(centres[which], widths[which]), v_lo, np.nextafter(v_hi, 0.))
+    nu = rng.normal(centres[which], widths[which])
+    if inside:
+        nu = nu[(nu > v_lo) & (nu < v_hi)]
+        table = table.subset(np.arange(table.num_lines) < nu.size)
+    else:
+        nu = np.clip(nu, v_lo, np.nextafter(v_hi, 0.))
     table.nu = np.sort(nu)
     return table
 

@@ -14,24 +14,8 @@ tables = {"uniform 400k": synthetic.line_table("CO2", 1., 5000.),
           "banded 400k": synthetic.banded_line_table("CO2", 1., 5000., num_lines=400_000, bands=8, seed=4),
           "banded 1.6M": synthetic.banded_line_table("CO2", 1., 5000., num_lines=1_600_000, bands=8, seed=5)}
 
-
-def dense_interior(num_lines, seed):
-    """Eight Gaussian bands well inside the grid (no lines clipped onto its ends, which
-    banded_line_table piles up at v_hi): what is dense here is dense the way a band centre is."""
-    table = synthetic.line_table("CO2", 1., 5000., num_lines, seed=seed)
-    rng = np.random.default_rng(seed + 77)
-    centres = rng.uniform(600., 4400., 8)
-    widths = rng.uniform(15., 80., 8)
-    which = rng.integers(0, 8, table.num_lines)
-    nu = rng.normal(centres[which], widths[which])
-    nu = nu[(nu > 1.) & (nu < 5000.)]
-    table = table.subset(np.arange(table.num_lines) < nu.size)
-    table.nu = np.sort(nu)
-    return table
-
-
-tables["interior 1.6M"] = dense_interior(1_600_000, 5)
-tables["interior 4M"] = dense_interior(4_000_000, 6)
+tables["interior 1.6M"] = synthetic.banded_line_table("CO2", 1., 5000., num_lines=1_600_000, bands=8, seed=5, inside=True)
+tables["interior 4M"] = synthetic.banded_line_table("CO2", 1., 5000., num_lines=4_000_000, bands=8, seed=6, inside=True)
 for name, table in tables.items():
     h = e.load(table)
     for scan in (1, 0):
