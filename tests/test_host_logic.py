@@ -281,7 +281,11 @@ def test_bench_starts_its_own_ranks_and_reports_the_worst_exit_code():
     environment = {k: v for k, v in os.environ.items()
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     result = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo",
-                             "--steps", "1", "--warmup", "0", "--launch-timeout", "120"],
+                             "--steps", "1", "--warmup", "0", "--launch-timeout", "120",
+                             # (the first rank to refuse must not have the other ended before it
+                             # has imported torch and refused as well: a loaded machine takes
+                             # longer over that import than the default five seconds)
+                             "--launch-grace", "100"],
                             capture_output=True, text=True, cwd=ROOT, env=environment, timeout=300)
     assert result.returncode == 1
     assert result.stdout.strip() == ""                 # no result line from a run that failed
