@@ -669,10 +669,16 @@ def launch_ranks(args, command=None):
         elif time.monotonic() > deadline:
             reason = f"no result after --launch-timeout {args.launch_timeout:g} s"
         if reason:
-            time.sleep(args.launch_grace)     # let the others print what they were doing
+            # Let the others print what they were doing: until they have all left, or the grace
+            # period is over.
+            patience = time.monotonic() + args.launch_grace
+            while time.monotonic() < patience and any(c.poll() is None for c in children):
+                time.sleep(0.05)
             own = [code for code in (child.poll() for child in children) if code is not None]
             stop(signal.SIGTERM)
-            time.sleep(min(3., args.launch_grace))
+            patience = time.monotonic() + min(3., args.launch_grace)
+            while time.monotonic() < patience and any(c.poll() is None for c in children):
+                time.sleep(0.05)
             stop(signal.SIGKILL)
             for child in children:
                 child.wait()
