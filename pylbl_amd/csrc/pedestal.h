@@ -115,16 +115,30 @@ struct PedestalWorkspace
     std::vector<int> host_counts;
 };
 
+constexpr int kRunCut = 1024;     // see opens_run
+
 inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cut_off)
 {
     const long long stride = 2*cut_off + 3;
-    const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2));
+    const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2) + n_lines/kRunCut);
     return n_lines*4 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 40) +
            4ll*(n_cells + stride)*8;
 }
 
+// A lane's value, the same in every lane (the lane index is wave-uniform): v_readlane.
+__device__ __forceinline__ double read_lane(double value, int lane)
+{
+    const long long bits = __double_as_longlong(value);
+    const int lo = __builtin_amdgcn_readlane((int)bits, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // A row opens a run when its window is not empty and differs from the previous row's
-// (an empty window in between also ends a run).
+// (an empty window in between also ends a run) -- and at every kRunCut-th row of the table: a
+// run is one wavefront's work in run_sums_kernel, row after row, and the recurrence holds for any
+// grouping of same-window rows, so thousands of lines in one window (a 4 M-line table has 8 000 to
+// the wavenumber at a band centre: 2.5 ms for that one wavefront) become several runs side by side.
 __device__ __forceinline__ int opens_run(const LineWing * __restrict__ wing,
                                          const int * __restrict__ sorted_of_row,
                                          long long r, long long n_lines)
@@ -132,7 +146,7 @@ __device__ __forceinline__ int opens_run(const LineWing * __restrict__ wing,
     if (r >= n_lines) return 0;
     const LineWing w = wing[sorted_of_row[r]];
     if (w.first > w.last) return 0;
-    if (r == 0) return 1;
+    if (r % kRunCut == 0) return 1;
     const LineWing p = wing[sorted_of_row[r - 1]];
     return (p.first == w.first && p.last == w.last) ? 0 : 1;
 }
@@ -302,12 +316,18 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
             {
                 const int rows = min(64, row_end - base);
                 __builtin_amdgcn_wave_barrier();    // the previous batch has been read
+                // Lane r keeps row r of the batch in registers as well: the row loop below takes
+                // what it needs of a row from there by v_readlane (wave-uniform, into scalar
+                // registers) and waits for no LDS round trip; the LDS copy serves settle_pairs,
+                // where every lane wants a different row.
+                StagedRow row;
+                row.centre = 0.; row.g2 = 1.; row.bl = 0.; row.repwid = 1.; row.y = 0.; row.amp = 0.;
+                row.first = -1; row.last = -2; row.core_first = 0; row.core_last = -1;
                 if (lane < rows)
                 {
                     const int j = sorted_of_row[base + lane];
                     const LineWing l = w[j];
                     const LineCore k = c[j];
-                    StagedRow row;
                     row.centre = l.centre; row.g2 = l.g2; row.bl = l.bl;
                     row.repwid = k.repwid; row.y = k.y; row.amp = k.amp;
                     row.first = l.first; row.last = l.last;
@@ -339,15 +359,18 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
                 };
                 for (int r = 0; r < rows; ++r)
                 {
-                    const StagedRow l = staged[r];
-                    if (l.first != head.first || l.last != head.last)
+                    if (__builtin_amdgcn_readlane(row.first, r) != head.first ||
+                        __builtin_amdgcn_readlane(row.last, r) != head.last)
                     {
                         open = false;
                         break;      // an empty or different window ends the run
                     }
-                    const bool in_core = active && point >= l.core_first && point <= l.core_last;
-                    const double d = v - l.centre;
-                    const double far_wing = l.bl*rcp_newton(__builtin_fma(d, d, l.g2));
+                    const int core_first = __builtin_amdgcn_readlane(row.core_first, r);
+                    const int core_last = __builtin_amdgcn_readlane(row.core_last, r);
+                    const bool in_core = active && point >= core_first && point <= core_last;
+                    const double d = v - read_lane(row.centre, r);
+                    const double far_wing = read_lane(row.bl, r)*
+                                            rcp_newton(__builtin_fma(d, d, read_lane(row.g2, r)));
                     total += in_core ? 0. : far_wing;
                     const unsigned long long cores = __ballot(in_core);
                     if (cores != 0ull)
@@ -429,21 +452,13 @@ __global__ __launch_bounds__(64) void run_sums_kernel(const LineWing * __restric
 // of this kept bit masks over the previous 256 runs and gave up beyond.)  What still costs
 // launches is a chain that matters ACROSS chunks: one launch per boundary it crosses.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double read_lane(double value, int lane)
-{
-    const long long bits = __double_as_longlong(value);
-    const int lo = __builtin_amdgcn_readlane((int)bits, lane);
-    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // Per level: [0] 1 while the relaxation applies (cleared by run_links_kernel where rows are too far
 // out of order, by the first relaxation launch where one window's runs are spread over more than
 // kMaxStretch runs: its total would be one lane's walk of thousands), [k] something
 // changed in relaxation launch k (k = 1 .. launches-1), [7] the number of launches queued.
 constexpr int kChainState = 8;
 constexpr int kMaxRelaxLaunches = 7;
-constexpr int kMaxStretch = 2048;
+constexpr int kMaxStretch = 1024;
 constexpr int kMaxHistory = 16384;  // earlier runs a run may have to look at (a 4 M-line table: 1 800)
 
 // A launch that changed nothing has verified the values it was handed.
