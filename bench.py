@@ -264,8 +264,10 @@ def profiled_traffic(workload, kernel="accumulate_kernel"):
     FETCH_SIZE / WRITE_SIZE passes, KiB units, reads doubled per the gfx950 correction) -- only
     if that profile ran this same workload."""
     import glob
+    # (newest = highest round tag in the name, r04e > r04a > r03e: a fresh checkout gives every
+    # file the same modification time)
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")),
-                   key=os.path.getmtime, reverse=True)
+                   key=os.path.basename, reverse=True)
     for path in paths:
         try:
             with open(path) as handle:
@@ -289,7 +291,7 @@ def profiled_issue(workload):
     the newest profiles/*_valu_counters.json of this workload (scripts/profile_counters.sh)."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_counters.json")),
-                   key=os.path.getmtime, reverse=True)
+                   key=os.path.basename, reverse=True)
     for path in paths:
         try:
             with open(path) as handle:
