@@ -359,3 +359,34 @@ def test_bench_launcher_ends_the_others_when_a_rank_fails_or_time_runs_out(tmp_p
     code, out, err = _launch(tmp_path, "import time; time.sleep(600)", gpus=2, timeout=1.)
     report = json.loads([x for x in err.splitlines() if x.startswith("{")][-1])
     assert code != 0 and "launch-timeout" in report["reason"]
+
+
+def test_bench_reads_the_newest_profile_by_its_round_tag():
+    """roofline.traffic / roofline.issue come from the committed rocprofv3 summaries of the same
+    workload; "newest" is the highest round tag in the file name (a fresh checkout gives every file
+    the same modification time)."""
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import bench
+    lines = sorted((ROOT / "profiles").glob("bench_r*.json"), key=lambda p: p.name, reverse=True)
+    workload = next(json.loads(p.read_text())["config"]["workload"] for p in lines
+                    if p.name.count("_") == 1)       # a default line: bench_<tag>.json
+    traffic, source = bench.profiled_traffic(workload)
+    summaries = sorted(p.name for p in (ROOT / "profiles").glob("r??[a-z]_summary.json"))
+    assert source == summaries[-1] and traffic > 0
+    issue = bench.profiled_issue(workload)
+    counters = sorted(p.name for p in (ROOT / "profiles").glob("r??[a-z]_valu_counters.json"))
+    assert issue["source"] == "profiles/" + counters[-1]
+
+
+def test_banded_tables_inside_the_grid_drop_what_falls_outside():
+    a = synthetic.banded_line_table("CO2", 1., 5000., num_lines=20000, bands=8, seed=5)
+    b = synthetic.banded_line_table("CO2", 1., 5000., num_lines=20000, bands=8, seed=5, inside=True)
+    assert a.num_lines == 20000 and np.all(np.diff(a.nu) >= 0)
+    assert b.num_lines <= 20000 and np.all(np.diff(b.nu) >= 0)
+    assert b.nu[0] > 1. and b.nu[-1] < 5000.
+    # nothing piled onto the ends of the range
+    assert np.count_nonzero(b.nu == b.nu[-1]) == 1 and np.count_nonzero(b.nu == b.nu[0]) == 1
+    for column in ("sw", "gamma_air", "delta_air", "local_iso_id"):
+        assert getattr(b, column).shape == (b.num_lines,)
