@@ -160,8 +160,9 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
 /* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1:
  * record HIP events around every kernel), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
  * pre-pass on a side stream, default 1), "scan_chain" (0/1: the pedestal recurrence by
- * relaxation where it applies, the serial chain behind it; default 1), "relax_launches" (2..7:
- * relaxation launches before the serial chain takes what has not settled; default 5),
+ * relaxation where it applies, the serial chain behind it; default 1), "relax_launches" (0, 2..7:
+ * relaxation launches before the serial chain takes what has not settled; 0 = three, or five for
+ * tables with more than two runs per window; default 0),
  * "skip_delivery_lanes" (0/1:
  * lbl_compute_streamed avoids the internal streams that share a hardware queue with the copy
  * stream; default 1), "farfield" (0/1: distant lines by power series, default

@@ -431,7 +431,7 @@ struct lbl_engine
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
     int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // pedestal chain by relaxation (pedestal.h), serial chain behind it
-    int relax_launches = 5;         // how many relaxation launches before the serial chain (2 ... 7)
+    int relax_launches = 0;         // relaxation launches before the serial chain (2 ... 7; 0: by the table)
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
@@ -2107,7 +2107,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->interp_shape = (int)value;
     }
-    else if (key == "relax_launches" && value >= 2 && value <= 7)
+    else if (key == "relax_launches" && (value == 0 || (value >= 2 && value <= 7)))
     {
         engine->relax_launches = (int)value;
     }

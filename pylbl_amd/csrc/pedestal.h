@@ -1091,13 +1091,12 @@ inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const
 // chain alone.
 inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                             const LineWing * wing, const LineCore * core, const GridSpec & g,
-                            int count, int n_cells, bool parallel_chain = true, int relax_launches = 5)
+                            int count, int n_cells, bool parallel_chain = true, int relax_launches = 0)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
     const int slot_stride = 2*g.cut_off + 3;
     const int n_bins = n_cells + 2*g.cut_off + 3;
-    relax_launches = std::min(std::max(relax_launches, 2), kMaxRelaxLaunches);
     ws.bin_sum.reserve((size_t)count*n_bins);
     ws.bin_end.reserve((size_t)count*n_bins);
     ws.cell_sum.reserve((size_t)count*n_cells);
@@ -1112,6 +1111,12 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
     for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
+    // How many relaxation launches to queue (0: by the table): three settle every table whose runs
+    // are about as many as its windows; where dozens of lines alternate between two windows at
+    // every integer wavenumber (a 4 M-line table: three runs per window) chains cross more chunk
+    // boundaries and five are needed.  Every launch is ~6 us of the host's time, used or not.
+    if (relax_launches <= 0) relax_launches = max_runs > 2*n_bins ? 5 : 3;
+    relax_launches = std::min(std::max(relax_launches, 2), kMaxRelaxLaunches);
     ws.runs.reserve((size_t)count*max_runs);
     ws.slot_sums.reserve((size_t)count*max_runs*slot_stride);
     hipLaunchKernelGGL(run_sums_kernel, dim3(std::min(max_runs, 65535), count), dim3(64), 0,

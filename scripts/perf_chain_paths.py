@@ -1,5 +1,5 @@
 """Pedestal pass time with the relaxation (scan_chain 1) and with the serial chain alone (0) for uniform,
-banded and very dense tables (one process).  LAUNCHES=n: relaxation launches (default 5)."""
+banded and very dense tables (one process).  LAUNCHES=n: relaxation launches (default 0: by the table)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -7,7 +7,7 @@ from pylbl_amd import synthetic
 from pylbl_amd.engine import DeviceSpectra, Engine
 e = Engine(0)
 e.set_option("farfield", 1)
-e.set_option("relax_launches", int(os.environ.get("LAUNCHES", "5")))
+e.set_option("relax_launches", int(os.environ.get("LAUNCHES", "0")))
 v0, vn, npv = 1, 5001, 1000
 out = DeviceSpectra(e, 1, (vn - v0)*npv)
 tables = {"uniform 400k": synthetic.line_table("CO2", 1., 5000.),
