@@ -475,6 +475,36 @@ def test_pedestal_relaxation_on_a_very_dense_table(engine, oracle):
     engine.free(molecule)
 
 
+def test_pedestal_with_shifts_of_several_wavenumbers(engine, oracle):
+    """At 50 atm a pressure shift of 0.05 cm-1/atm moves a line by 2.5 cm-1: rows of an ascending
+    table end up several windows out of order, the relaxation's premise (every earlier run has a
+    bin <= this one's + 1) fails on the device and that level goes to the serial chain -- while the
+    level at 0.5 atm of the same call keeps the relaxation.  Both against the oracle."""
+    from pylbl_amd import synthetic
+    table = synthetic.line_table("CO2", 590., 700., num_lines=6000, seed=97, tips_range=(150, 400))
+    table.delta_air = np.random.default_rng(8).choice([-0.06, -0.02, 0., 0.03, 0.06], table.num_lines)
+    t = np.asarray([250., 260., 240.])
+    p = np.asarray([5.e4, 5.e6, 2.e6])
+    x = np.asarray([4.e-4, 4.e-4, 1.e-3])
+    shifted = np.floor(table.nu + p[1]*9.86923e-6*table.delta_air)
+    assert np.max(np.maximum.accumulate(shifted)[:-1] - shifted[1:]) >= 2      # far out of order
+    molecule = engine.load(table)
+    v0, vn, npv = 610, 680, 50
+    try:
+        got = engine.compute(molecule, t, p, x, v0, vn, npv, remove_pedestal=True)
+        plain = engine.compute(molecule, t, p, x, v0, vn, npv)
+        case = golden_io.Case("shifts", 0, 0, 0, 0, v0, vn, npv, 25, True, None, 0)
+        for level in range(3):
+            k_ref, _ = oracle.absorption_port(table, t[level], p[level], x[level], v0, vn, npv,
+                                              remove_pedestal=True)
+            assert_spectrum(got[level], k_ref, case, f"level {level} at {p[level]:g} Pa",
+                            plain[level],
+                            conditioning=lambda: oracle_conditioning(
+                                oracle, table, t[level], p[level], x[level], v0, vn, npv, 25, k_ref))
+    finally:
+        engine.free(molecule)
+
+
 def test_empty_and_degenerate_inputs(engine, oracle):
     """Empty table, a table with no line in reach of the grid, a single line, a one-cell grid,
     a cut-off wider than the grid."""
