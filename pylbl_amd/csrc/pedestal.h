@@ -764,11 +764,13 @@ __global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ 
     }
 }
 
-constexpr int kChainChunk = 32;     // runs whose slot sums are staged in LDS at a time
+constexpr int kChainChunk = 16;     // runs whose slot sums are staged in LDS at a time
 // Small-LDS form: the slots of the spectrum live in HBM, kChainRing consecutive ones of them in LDS
 // (the register window moves inside that ring at the price of an LDS round trip; only when it
-// leaves the ring -- every ~380 bins of a sorted table -- does the chain wait for HBM).
-constexpr int kChainRing = 512;
+// leaves the ring -- every ~140 bins of a sorted table -- does the chain wait for HBM).  Staging
+// and ring together ask for 15.5 KB: less than one accumulate workgroup holds, so the kernel -- which
+// usually only reads the flags and leaves -- finds a place on a busy chip at once.
+constexpr int kChainRing = 256;
 constexpr int kChainRingBack = 64;  // slots kept behind the window that re-bases the ring
 
 // One wavefront per level: the serial recurrence over runs.  Slots (the accumulated
