@@ -1,7 +1,10 @@
+#!/bin/bash
+# Durations of run_chain_kernel (which, behind a relaxation that settled, only reads the flags and leaves)
+# beside the direct accumulate kernel, per build of the library: bash scripts/experiments/settle_cmp.sh <name> ...
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
 cp pylbl_amd/liblbl_amd.so /tmp/orig.so
-for name in masks current; do
-  if [ $name = masks ]; then cp build/liblbl_masks.so pylbl_amd/liblbl_amd.so; else cp /tmp/orig.so pylbl_amd/liblbl_amd.so; fi
+for name in "$@"; do
+  cp build/liblbl_$name.so pylbl_amd/liblbl_amd.so
   rm -rf gpurun_out/settles_$name
   rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/settles_$name -- python3 scripts/experiments/chain_settles.py 100 > /dev/null 2>&1
   python3 - <<PY
