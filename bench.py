@@ -21,8 +21,8 @@ every rank gets --levels-per-gpu levels (default 1).
 Besides the contract's keys the line carries (N = 1): `roofline` (the resource that binds the
 dominant kernel: the fp64 vector ALU), `roofline_hbm_algorithmic` (SURVEY 8d's 24 B/eval figure,
 for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure what users run:
-`sustained`, `pedestal_option`, `standard_atmosphere_option`, `banded_table_option`,
-`dense_table_option`,
+`sustained`, `lane_overlap_option`, `pedestal_option`, `standard_atmosphere_option`,
+`banded_table_option`, `dense_table_option`,
 `small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`.
 """
 import argparse
@@ -82,7 +82,7 @@ def parse():
                         help="only the timed steps (what scripts/profile_bench.sh profiles)")
     parser.add_argument("--extras", default="all",
                         help="comma list of untimed legs: all, none, or any of sustained, "
-                             "pedestal, atmosphere, banded, dense, small, farfield, api, continuum")
+                             "overlap, pedestal, atmosphere, banded, dense, small, farfield, api, continuum")
     parser.add_argument("--farfield", action="store_true",
                         help="engine option farfield=1: distant lines through their power "
                              "series (an algorithmic shortcut; never the headline value)")
@@ -1117,6 +1117,21 @@ def run():
                 engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
                 remove_pedestal=args.pedestal, min_seconds=2.,
                 label="the timed step repeated for >= 2 s (clocks at their sustained level)")
+        if leg("overlap") and not args.pedestal and args.config == "target":
+            # The timed step queues its plain calls back to back on one stream (a launch then takes
+            # what it takes alone, which is what `roofline` divides by).  Letting them take turns on
+            # two lanes like the calls with a pedestal do -- the next call's prologue and the tail of
+            # this one's accumulate grid overlap -- is an engine option (small_points): the same step
+            # that way, for the record.
+            engine.set_option("small_points", 1 << 30)
+            try:
+                line["lane_overlap_option"] = lines_leg(
+                    engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+                    remove_pedestal=False, ring=2,
+                    label="the timed step with its calls taking turns on two lanes "
+                          "(engine option small_points = 2^30), two sets of output blocks")
+            finally:
+                engine.set_option("small_points", 1 << 20)
         if leg("pedestal") and not args.pedestal:
             line["pedestal_option"] = lines_leg(
                 engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
