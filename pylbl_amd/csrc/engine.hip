@@ -1578,12 +1578,20 @@ int compute(lbl_engine * engine, const ComputeRequest & rq, hipEvent_t * wait_fo
                 f.n_cells = n_cells;
                 f.n_per_v = g.n_per_v;
                 f.flags = rq.flags;
+                // (a run of tiles may be empty -- few tiles, uneven weights -- and must not move
+                // its neighbours' bounds: entry i is both the end of run i-1 and the start of run i)
+                long long reached = 0;
                 for (int piece = 0; piece < pieces; ++piece)
                 {
                     long long q0, q1;
                     point_range(piece, q0, q1);
+                    if (q1 <= q0)
+                    {
+                        q0 = q1 = reached;
+                    }
                     f.point_begin[piece] = q0;
-                    f.point_begin[piece + 1] = std::max(q1, q0);
+                    f.point_begin[piece + 1] = q1;
+                    reached = q1;
                 }
                 f.sums = sums;
                 f.sums_stride = sums_stride;

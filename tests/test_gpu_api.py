@@ -973,3 +973,37 @@ def test_gas_output_does_not_depend_on_who_delivers():
         scale = np.max(np.abs(parts[name]), axis=-1, keepdims=True)
         assert np.max(np.abs(each[name] - last[name])/scale) < 1.e-13, name
         assert np.max(np.abs(each[name] - parts[name])/scale) < 1.e-13, name
+
+
+@pytest.mark.parametrize("remove_pedestal", [False, True])
+def test_streamed_call_with_empty_runs_of_tiles(remove_pedestal):
+    """Four tiles, every line of the table beyond the end of the grid (within the cut-off of its
+    last tile only): the runs of tiles come out as [0, 3), [3, 4) and two EMPTY ones -- which used
+    to move the end of the run before them to zero, so that with a pedestal its columns were
+    neither given it nor delivered (found by the Spectroscopy fuzz once every gas delivered its
+    block run by run; the bounds of run i are entries i and i+1 of one array)."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CH4", 975., 984., num_lines=46, seed=3, tips_range=(150, 400))
+    atmos = synthetic.standard_atmosphere(3)
+    v0, vn, npv = 909, 959, 10
+    n = (vn - v0)*npv
+    h = e.load(table)
+    x = atmos.vmr["CH4"]
+    for farfield in (True, False):
+        expect = e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal,
+                           scale_density=True, farfield=farfield)
+        assert expect[:, 400:].any()                    # something to lose in the last tile
+        for pieces in (2, 4, 8):
+            out = DeviceSpectra(e, 3, n)
+            target = e.host_array((3, n - 3))
+            target[...] = -1.
+            e.compute(h, atmos.t, atmos.p, x, v0, vn, npv, remove_pedestal=remove_pedestal,
+                      out=out, scale_density=True, farfield=farfield, asynchronous=True,
+                      deliver=target, pieces=pieces)
+            e.synchronize()
+            assert np.array_equal(target, expect[:, :n - 3]), (farfield, pieces)
+            assert np.array_equal(out.to_host(), expect), (farfield, pieces)
+            out.free()
+    e.free(h)
+    e.close()

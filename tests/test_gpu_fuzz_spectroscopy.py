@@ -1,6 +1,6 @@
 """Seeded random atmospheres through Spectroscopy.compute_absorption(): random levels, gases,
 grids, line tables, cross-section files and output formats, every mechanism slot checked
-against the composition of the three oracles (6 cases; PYLBL_FUZZ_SPECTROSCOPY=100 to soak)."""
+against the composition of the three oracles (64 cases; PYLBL_FUZZ_SPECTROSCOPY=1000 to soak)."""
 import os
 
 import numpy as np
@@ -17,7 +17,7 @@ CONTINUA = {"H2O": ("H2OForeign", "H2OSelf"), "CO2": ("CO2",), "O3": ("O3",), "O
             "N2": ("N2",)}
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PYLBL_FUZZ_SPECTROSCOPY", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PYLBL_FUZZ_SPECTROSCOPY", "64"))))
 def test_random_atmosphere(tmp_path, oracle, continuum_oracle, seed):
     from oracle import xsec_oracle
     rng = np.random.default_rng(31_000 + seed)
