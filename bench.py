@@ -699,6 +699,9 @@ def launch_ranks(args, command=None):
     codes = [child.returncode for child in children]
     if not reason:
         own = codes
+        failed = [r for r, code in enumerate(codes) if code != 0]
+        if failed:          # (every rank had left between two looks at them)
+            reason = f"rank {failed[0]} left with code {codes[failed[0]]}"
     # The worst code among the ranks that left by themselves (the ones this launcher ended do not
     # count); 124, like timeout(1), when time ran out with none of them having failed.
     worst = max([(128 - code if code < 0 else code) for code in own] or [0])
