@@ -126,7 +126,12 @@ int lbl_compute(lbl_engine *engine, int32_t molecule, int32_t n_levels,
  * copies to overlap) beside the kernels of the next run.  What the reference's callers get --
  * a host array per call (gas_optics.py:65,91) -- without a copy behind the last kernel.  The
  * values are those of lbl_compute (same kernels, same order of additions).  With LBL_ASYNC the
- * copies are complete after lbl_synchronize. */
+ * copies are complete after lbl_synchronize -- and until then the copied part of `k` must not be
+ * written again: the engine orders calls by the memory they WRITE (two calls into one block run
+ * in the order they were made), not by what a copy still reads; the same holds for
+ * lbl_copy_rows_to_host with LBL_ASYNC.  (An event behind every copy, for later writers to wait
+ * for, was measured: it takes the copies' back-to-back rate away, 3.3 -> 3.6 ms for the call that
+ * delivers four blocks.) */
 int lbl_compute_streamed(lbl_engine *engine, int32_t molecule, int32_t n_levels,
                          const double *temperature, const double *pressure, const double *vmr,
                          int32_t v0, int32_t vn, int32_t n_per_v, int32_t cut_off,

@@ -529,6 +529,9 @@ struct lbl_engine
     {
         Lane::Finish & f = lane.finish;
         hipStream_t stream = lane.main;
+        // (what is queued here is queued NOW: a call that joined this lane since the kept-back
+        // call was made has to join it again)
+        lane.used = true;
         if (f.order_writers)
         {
             order_after_writers(f.finish_stream, f.k, f.out_bytes, &lane);
