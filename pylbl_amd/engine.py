@@ -384,7 +384,9 @@ class Engine(object):
         """Cross sections [m2] for every level: returns float64[levels, (vn-v0)*n_per_v]
         (or fills `out`: a host array or a DeviceSpectra).
 
-        deliver: with a device `out`, a float64 [levels, columns] host view with contiguous rows
+        deliver: (until engine.synchronize() the delivered part of `out` must not be written again:
+        calls are ordered by the memory they write, not by what a copy still reads.)
+        With a device `out`, a float64 [levels, columns] host view with contiguous rows
         (page-locked: Engine.host_array) that receives the first `columns` points of every level
         while the call computes, in `pieces` runs of tiles (lbl_compute_streamed).
         defer_finish: keep the call's last kernels (the ones that touch `out`) back until
