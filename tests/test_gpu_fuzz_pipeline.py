@@ -31,6 +31,10 @@ def test_pipeline(engine, seed):
     npv = int(rng.choice([10, 100, 1000]))
     v0 = int(rng.integers(1, 3000))
     span = int(rng.integers(3, max(4, min(60, 600_000//npv))))
+    if rng.random() < 0.15:
+        # more than 2^20 points: plain calls then queue on one lane and join the others by events
+        # instead of taking turns on them (engine option small_points)
+        npv, span = 1000, int(rng.integers(1060, 1300))
     vn = v0 + span
     n = span*npv
     lo, hi = max(v0 - 26., 0.05), vn + 26.
