@@ -263,14 +263,32 @@ class ShardedLines(object):
         order_on_device: None (default; $PYLBL_AMD_ORDER_ON_DEVICE=1 turns it on): `order` is
               used when the exchange stays on the device (nccl), `flush` otherwise.  True: `order`
               whenever the blocks are on a device.
+        order_compute: Callable that orders everything `compute` queues from now on behind what
+              the exchange library's stream on `device` holds now (for_engine: the engine's
+              streams wait for torch's current stream); None: nothing `compute` queues runs on a
+              stream of its own.
+        collect_limit: bytes; a collected array of at most half of this is kept twice (used in
+              turn, like the per-rank blocks), a larger one once.
+        always_exchange: go through the collection step also with ONE rank in the group (the
+              rank's blocks are copied into the collected array on the exchange library's stream,
+              ordered behind the kernels as for N ranks): what a one-GPU box can run of the RCCL
+              path's ordering.
 
     Memory on the receiving rank: the collected array ([L, n] for "total", [molecules, L, n] for
-    "gas") is allocated once and kept; together with that rank's own blocks (two sets, used in
-    turn) BASELINE config 5 in "gas" mode needs 164 GB + 2 x 20.5 GB of its 288 GB, "total" mode
-    20.5 GB + 2 x 2.6 GB.
+    "gas") is allocated once and kept -- two of it (used in turn, a result stays valid until the
+    call after next) while both fit `collect_limit` (96 GB), else one: BASELINE config 5 in "gas"
+    mode needs 164 GB + 2 x 20.5 GB (the rank's own blocks) of its 288 GB, "total" mode
+    2 x 20.5 GB + 2 x 2.6 GB.
+
+    Ordering between calls: every kept buffer remembers the exchange that last read or wrote it,
+    and whoever writes it next is ordered behind that exchange first -- on the device (the
+    writer's stream waits; RCCL) or by waiting for it (host tensors; gloo).  Calls may therefore
+    be queued back to back with async_op without waiting for their Pendings; what is lost by not
+    waiting is only a result that a later call has overwritten.
     """
     def __init__(self, compute, molecules, n, weights=None, group=None, device="cpu",
-                 flush=None, order=None, zero=None, order_on_device=None):
+                 flush=None, order=None, zero=None, order_on_device=None, order_compute=None,
+                 collect_limit=96 << 30, always_exchange=False):
         self.compute = compute
         self.molecules = list(molecules)
         self.n = int(n)
@@ -288,19 +306,27 @@ class ShardedLines(object):
             import os
             order_on_device = True if os.environ.get("PYLBL_AMD_ORDER_ON_DEVICE") == "1" else None
         self.order_on_device = order_on_device
+        self.order_compute = order_compute
+        self.collect_limit = int(collect_limit)
+        self.always_exchange = bool(always_exchange)
         self._buffers = {}
+        self._users = {}                # buffer key -> the Pending that last read or wrote it
         self._turn = 0
         self.last_exchange = None       # the Pending of the latest call with world > 1
 
     @classmethod
     def for_engine(cls, engine, handles, grid_args, remove_pedestal=False, scale_density=False,
-                   range_policy="reference", weights=None, group=None, order_on_device=None):
+                   range_policy="reference", weights=None, group=None, order_on_device=None,
+                   farfield=False, cut_off=25, always_exchange=False):
         """Per-rank compute on an MI355X: the engine writes spectra straight into torch CUDA
         tensors (torch only owns the memory and runs the exchange).
 
         Args:
             handles: {formula: engine molecule handle} (insertion order = reporting order).
             grid_args: (v0, vn, n_per_v) as pyLBL/c_lib/gas_optics.py:61-63 derives them.
+            farfield: distant lines through their power series (LBL_FARFIELD; what
+                      Spectroscopy runs by default).
+            cut_off: as Gas.absorption_coefficient's (pyLBL/c_lib/gas_optics.py:46-47).
         """
         import torch
         v0, vn, n_per_v = grid_args
@@ -313,9 +339,10 @@ class ShardedLines(object):
         def compute(formula, temperature, pressure, vmr, out, accumulate):
             if len(temperature):
                 engine.compute(handles[formula], temperature, pressure, vmr, v0, vn, n_per_v,
-                               remove_pedestal=remove_pedestal, scale_density=scale_density,
-                               range_policy=range_policy, out=Slot(out), accumulate=accumulate,
-                               asynchronous=True)
+                               cut_off=cut_off, remove_pedestal=remove_pedestal,
+                               scale_density=scale_density, range_policy=range_policy,
+                               out=Slot(out), accumulate=accumulate, asynchronous=True,
+                               farfield=farfield)
         device = torch.device("cuda", engine.device)
 
         def order():
@@ -323,26 +350,62 @@ class ShardedLines(object):
             # engine's streams; the exchange torch launches next is ordered behind that stream.
             engine.order_stream_after(torch.cuda.current_stream(device).cuda_stream)
 
+        def order_compute():
+            # the other way round: what the engine queues next waits for torch's current stream
+            # (which an exchange's work object has just been made to wait for).
+            engine.order_after_stream(torch.cuda.current_stream(device).cuda_stream)
+
         def zero(tensor):
             engine.fill_zero(Slot(tensor), asynchronous=True)
         return cls(compute, list(handles), n, weights=weights, group=group, device=device,
                    flush=engine.synchronize, order=order, zero=zero,
-                   order_on_device=order_on_device)
+                   order_on_device=order_on_device, order_compute=order_compute,
+                   always_exchange=always_exchange)
 
     # -- buffers -----------------------------------------------------------------------------
-    def _buffer(self, name, shape, zero=False, sets=2):
+    def _buffer(self, name, shape, zero=False, sets=2, writer="compute"):
         """Per-rank blocks are kept between calls, two of each so that an exchange still in
-        flight (async_op) is not overwritten by the next call (sets=1: one, for what only the
-        exchange itself writes)."""
+        flight (async_op) is not overwritten by the next call (sets=1: one, for a collected
+        array too large to keep twice).  Whoever is about to write the buffer -- `compute`
+        (the engine's streams) or the exchange library's stream ("exchange") -- is first ordered
+        behind the exchange that last used it (_settle)."""
         import torch
         key = (name, self._turn % sets, tuple(shape))
         tensor = self._buffers.get(key)
         if tensor is None:
             tensor = torch.empty(shape, dtype=torch.float64, device=self.device)
             self._buffers[key] = tensor
+        self._settle(key, writer)
+        self._last_key = key
         if zero:
             self._zero(tensor)
         return tensor
+
+    def _settle(self, key, writer):
+        """Orders the next writer of buffer `key` behind the exchange that last read or wrote it
+        (if that is still in flight).  Host tensors: the host waits for the exchange (gloo's
+        requests complete inside wait() only).  Device tensors: the exchange library's current
+        stream waits for the exchange's work objects -- no host wait -- and, when the writer is
+        `compute`, the engine's streams are then ordered behind that stream."""
+        pending = self._users.pop(key, None)
+        if pending is None or pending.done:
+            return
+        if pending.device is None:
+            pending.wait()
+            return
+        import torch
+        with torch.cuda.device(pending.device):
+            for request in pending.requests:
+                request.wait()              # nccl: orders torch's current stream, not the host
+        if writer == "compute":
+            if self.order_compute is not None:
+                self.order_compute()
+            else:
+                torch.cuda.current_stream(pending.device).synchronize()
+
+    def _used_by(self, pending, keys):
+        for key in keys:
+            self._users[key] = pending
 
     def _zero(self, tensor):
         """With the engine's own fill the zeroes are ordered like a compute call.  Otherwise
@@ -372,11 +435,13 @@ class ShardedLines(object):
         Returns:
             On rank `dst` (every rank if dst is None) the result, elsewhere None (dict of None
             for "gas"); or a Pending that yields it.  The tensors returned are buffers this
-            object keeps and writes again: with one rank the rank's own blocks, of which there are
-            two sets used in turn (contents valid until the call after next); with several ranks
-            the collected array, of which there is ONE (contents valid until the next call's
-            exchange -- wait for a Pending and use or copy its result before calling run() again;
-            successive exchanges are ordered on the exchange library's stream).
+            object keeps and writes again: with one rank the rank's own blocks, with several the
+            collected array -- two sets of either, used in turn, so contents are valid until the
+            call after next (a collected array above collect_limit/2 is kept ONCE: valid until
+            the next call's exchange -- wait for its Pending and use or copy the result before
+            calling run() again).  Not waiting is safe for everything but the overwritten
+            result: a buffer's next writer is ordered behind the exchange that last used it
+            (see the class docstring).
         """
         import torch
         import torch.distributed as dist
@@ -394,9 +459,11 @@ class ShardedLines(object):
         through_host = on_device and world > 1 and backend != "nccl"
 
         # 1. compute this rank's units into its blocks
+        used = []               # keys of the kept buffers this call's exchange reads or writes
         if output == "total":
             # One [levels touched, n] block; every molecule adds to the rows of its levels.
             block = self._buffer("total", (len(my_levels), n))
+            used.append(self._last_key)
             first = True
             for m, levels in sorted(mine.items()):
                 rows = [row[level] for level in levels]
@@ -421,10 +488,11 @@ class ShardedLines(object):
             blocks = {}
             for m, levels in sorted(mine.items()):
                 blocks[m] = self._buffer(("gas", m), (len(levels), n))
+                used.append(self._last_key)
                 self.compute(self.molecules[m], temperature[levels], pressure[levels],
                              x[self.molecules[m]][levels], blocks[m], False)
         # 2. one rank: done (with async_op the kernels stay queued until wait())
-        if world == 1:
+        if world == 1 and not (self.always_exchange and backend is not None):
             if output == "total":
                 result = blocks[None]
             else:
@@ -445,6 +513,7 @@ class ShardedLines(object):
 
         if through_host:
             blocks = {key: value.cpu() for key, value in blocks.items()}
+            used = []           # the exchange reads host copies made just now, not the kept blocks
         where = "cpu" if (through_host or not on_device) else self.device
         wait_on = None if where == "cpu" else self.device
         sizes = {key: value.numel()*8 for key, value in blocks.items()}
@@ -454,8 +523,12 @@ class ShardedLines(object):
         i_receive = rank in receivers
         if output == "total" and plan.mode == "units":
             # The molecules of one level sit on several ranks: a real sum over ranks.
-            partial = self._buffer("reduce", (n_levels, n), sets=1) if where != "cpu" else \
-                torch.empty((n_levels, n), dtype=torch.float64)
+            if where != "cpu":
+                partial = self._buffer("reduce", (n_levels, n), writer="exchange",
+                                       sets=2 if 16*n_levels*n <= self.collect_limit else 1)
+                used.append(self._last_key)
+            else:
+                partial = torch.empty((n_levels, n), dtype=torch.float64)
             partial.zero_()
             for i, level in enumerate(my_levels):
                 partial[level] = blocks[None][i]
@@ -472,19 +545,25 @@ class ShardedLines(object):
                               peers=[r for r in range(world) if r != rank],
                               bytes_sent=partial.numel()*8,
                               bytes_received=partial.numel()*8 if i_receive else 0)
+            self._used_by(pending, used)
             self.last_exchange = pending
             return pending if async_op else pending.wait()
 
         # Grouped point-to-point gather: every block goes straight into its final place.
-        # The collected array is kept between calls -- ONE of it: "gas" output of BASELINE config
-        # 5 is 164 GB on the receiving rank, two would not fit its 288 GB (successive exchanges
-        # write it in the order they were started; see run()'s Returns).
+        # The collected array is kept between calls -- two of it, used in turn, unless it is too
+        # large for that: "gas" output of BASELINE config 5 is 164 GB on the receiving rank, two
+        # would not fit its 288 GB (then ONE: its next writer is ordered behind the exchange still
+        # using it, _settle; see run()'s Returns).
         def collected(shape):
             if not i_receive:
                 return None
             if where == "cpu":
                 return torch.empty(shape, dtype=torch.float64)
-            return self._buffer("final", shape, sets=1)
+            nbytes = 8*int(np.prod(shape))
+            tensor = self._buffer("final", shape, writer="exchange",
+                                  sets=2 if 2*nbytes <= self.collect_limit else 1)
+            used.append(self._last_key)
+            return tensor
         if output == "total":
             final = collected((n_levels, n))
             pieces = lambda r: [(None, plan.levels_of(r))]                      # noqa: E731
@@ -527,6 +606,7 @@ class ShardedLines(object):
                           describe=f"grouped send/recv of the {output!r} blocks to "
                                    f"{'every rank' if dst is None else f'rank {dst}'}",
                           peers=sorted(peers), bytes_sent=sent, bytes_received=received)
+        self._used_by(pending, used)
         self.last_exchange = pending
         return pending if async_op else pending.wait()
 

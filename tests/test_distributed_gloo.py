@@ -227,3 +227,65 @@ def test_exchange_timeout_names_the_rank_and_its_peers():
     message, seconds = results[0]
     assert "rank 0" in message and "[1]" in message and "not complete after 1 s" in message
     assert "B to receive" in message and seconds < 3.5
+
+
+def _back_to_back_worker(rank, port, n_levels, output, dst, queue):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    formulas = ("H2O", "CO2", "O3")
+
+    def compute(formula, temperature, pressure, x, out, accumulate):
+        rows = torch.from_numpy(np.asarray(temperature)*1000. + formulas.index(formula))
+        if accumulate:
+            out += rows[:, None]
+        else:
+            out.copy_(rows[:, None].expand_as(out))
+    sharded = distributed.ShardedLines(compute, formulas, 4096, weights=[3., 2., 1.])
+    pendings, temperatures = [], []
+    for call in range(4):
+        t = 200. + 10.*call + np.arange(n_levels, dtype=np.float64)
+        temperatures.append(t)
+        # No wait between the calls: the fourth writes the per-rank blocks the second's exchange
+        # read, the third those of the first.
+        pendings.append(sharded.run(t, t*100., {f: t*1e-6 for f in formulas}, dst=dst,
+                                    output=output, async_op=True))
+    ok = True
+    for t, pending in zip(temperatures, pendings):
+        out = pending.wait()
+        receives = dst is None or rank == dst
+        if not receives:
+            ok = ok and (out is None or all(v is None for v in out.values()))
+        elif output == "total":
+            expect = sum(t*1000. + m for m in range(3))
+            ok = ok and bool(np.array_equal(out.numpy(), np.repeat(expect[:, None], 4096, axis=1)))
+        else:
+            for m, f in enumerate(formulas):
+                ok = ok and bool(np.array_equal(out[f].numpy(),
+                                                np.repeat((t*1000. + m)[:, None], 4096, axis=1)))
+    queue.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_levels,output,dst", [(5, "gas", 0), (4, "total", 1), (1, "total", None),
+                                                 (1, "total", 0)])
+def test_calls_queued_back_to_back_without_waiting(n_levels, output, dst):
+    """four asynchronous calls in a row, none waited for until all are queued -- every
+    one of them must still deliver its own result (a buffer's next writer is ordered behind the
+    exchange that last used it)."""
+    import torch.multiprocessing as mp
+    context = mp.get_context("spawn")
+    queue = context.Queue()
+    port = _free_port()
+    procs = [context.Process(target=_back_to_back_worker,
+                             args=(r, port, n_levels, output, dst, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(queue.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == [(0, True), (1, True)]
