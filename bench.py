@@ -23,7 +23,15 @@ dominant kernel: the fp64 vector ALU), `roofline_hbm_algorithmic` (SURVEY 8d's 2
 for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure what users run:
 `sustained`, `lane_overlap_option`, `pedestal_option`, `standard_atmosphere_option`,
 `banded_table_option`, `dense_table_option`,
-`small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`.
+`small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`,
+the other BASELINE configs at one GPU's size -- `config2_option` (8 molecules, 5 M points),
+`config3_share_option` (one rank's 8 of the 64 standard-atmosphere levels, through
+ShardedLines.for_engine) and `config4_share_option` (4 of a rank's 32 levels x 8 molecules at
+10 M points, summed over the gases on the device), each with a roofline fraction from launches
+timed alone -- and `ingest`: what it costs to get a molecule's line table from the reference's
+SQLite file into HBM by each route (load time reported separately), with
+`cpu_baseline` split into the reference's per-call read and its Voigt loop.
+`environment` echoes every PYLBL_AMD_* variable that was in effect.
 """
 import argparse
 import json
@@ -109,6 +117,16 @@ def parse():
     parser.add_argument("--cpu-workers", type=int, default=16,
                         help="processes of cpu_baseline_parallel (16 = one GPU's share of the "
                              "host on this pool; pass the host's core count to use them all)")
+    parser.add_argument("--cpu-all-cores", type=int, default=-1,
+                        help="processes of cpu_baseline_all_cores: -1 = every hardware thread this "
+                             "process may run on (os.sched_getaffinity), 0 = skip the leg")
+    parser.add_argument("--cpu-pool-timeout", type=float, default=45.,
+                        help="seconds the all-cores pool may take to start and run before the leg "
+                             "is given up (and says so)")
+    parser.add_argument("--force-group", action="store_true",
+                        help="initialise the torch.distributed process group also at N = 1 (with "
+                             "--backend nccl: RCCL loads and a communicator is made on one GPU) and "
+                             "run the step through the collection path of ShardedLines")
     return parser.parse_args()
 
 
@@ -149,10 +167,16 @@ def cpu_model():
 # ---------------------------------------------------------------------------------------------
 # CPU baselines (the only place bench.py touches oracle/)
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal):
+def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal, db=None):
     """Times the CPU path on level 0 of the same workload (the whole grid unless --cpu-sample-cm
     bounds it): the reference's own compiled C reading SQLite when oracle/_ref is present
-    ("reference"), else our C restatement ("port").  One thread, like the reference."""
+    ("reference"), else our C restatement ("port").  One thread, like the reference.
+
+    The reference pays for its database on EVERY call (absorption.c:44-86: open, id / TIPS / mass
+    look-ups, a full scan of the molecule's rows, five transcendental calls per row).  `split`
+    separates that from the Voigt loop: the same call on the same file at ONE point per cm-1
+    (the loop shrinks to 52 evaluations per line, ~0.1 % of the fine grid's) is the per-call
+    cost that does not depend on the resolution; the rest is the loop (voigt.c:21-25,74-189)."""
     import tempfile
     from oracle import oracle
     from pylbl_amd.database import write_database
@@ -162,9 +186,10 @@ def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal
     kind = "reference" if oracle.have_reference() else "port"
     seconds = 0.
     port_seconds = 0.
+    read_seconds = 0.
+    coarse_evals = 0
     with tempfile.TemporaryDirectory() as tmp:
-        db = None
-        if kind == "reference":
+        if kind == "reference" and (db is None or vn != vn_full):
             db = write_database(os.path.join(tmp, "sample.db"), sample)
         for t in sample:
             args = (atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], v0, vn, n_per_v)
@@ -179,6 +204,11 @@ def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal
                 # (window lengths, spectra.c:48-62), checked against the restatement's own
                 # counter by tests/test_host_logic.py.
                 evals += closed_form_evals(t, atmos.p[0], v0, vn, n_per_v)
+                start = time.perf_counter()
+                rc, _ = oracle.absorption_reference(db, t.formula, *args[:5], 1,
+                                                    remove_pedestal=remove_pedestal)
+                read_seconds += time.perf_counter() - start
+                coarse_evals += closed_form_evals(t, atmos.p[0], v0, vn, 1)
             else:
                 start = time.perf_counter()
                 _, extras = oracle.absorption_port(t, *args, remove_pedestal=remove_pedestal)
@@ -187,7 +217,7 @@ def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal
     if kind == "port":
         seconds = port_seconds
     whole = vn == vn_full
-    return {
+    out = {
         "value": evals/seconds, "unit": "evals/s", "cores": 1, "kind": kind,
         "sample": f"level 0, {'+'.join(t.formula for t in sample)}, "
                   f"{'the whole grid' if whole else 'grid sample'} {v0}-{vn} cm-1 at "
@@ -197,6 +227,20 @@ def cpu_baseline(tables, atmos, v0, vn_full, n_per_v, sample_cm, remove_pedestal
                      if kind == "reference" else ""),
         "cpu": cpu_model(), "host_cores": os.cpu_count(),
     }
+    if kind == "reference":
+        loop = max(seconds - read_seconds, 1e-9)
+        out["split"] = {
+            "total_s": seconds, "read_and_line_scalars_s": read_seconds, "voigt_loop_s": loop,
+            "read_fraction": read_seconds/seconds,
+            "voigt_loop_evals_per_s": (evals - coarse_evals)/loop,
+            "read_s_per_molecule": read_seconds/max(len(sample), 1),
+            "note": "read_and_line_scalars_s = the same reference call on the same file at 1 "
+                    "point per cm-1 (database open, look-ups, every row stepped and prepared: "
+                    "absorption.c:44-86, spectra.c:17-45; its 52 evaluations per line are "
+                    f"{coarse_evals:.3g} of the {evals:.3g}); voigt_loop_s = total - that; the "
+                    "reference pays the read on every (level, molecule) call, this engine once "
+                    "per molecule (`ingest`)"}
+    return out
 
 
 def closed_form_evals(table, pressure, v0, vn, n_per_v, cut_off=25):
@@ -226,10 +270,12 @@ def _cpu_chunk(job):
     return extras["evals"]
 
 
-def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, workers):
+def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, workers, timeout=None,
+                          why=None):
     """What a user could do with multiprocessing around the reference's Gas: independent
     (molecule, sub-grid) units of the same grid farmed out over `workers` processes (our C
-    restatement on arrays; pedestal off, the units would not be independent with it)."""
+    restatement on arrays; pedestal off, the units would not be independent with it).
+    timeout: seconds the pool may take (start-up included) before the leg is given up."""
     import multiprocessing
     vn = vn_full if sample_cm <= 0 else min(vn_full, v0 + int(sample_cm))
     pieces = max(4*workers, 1)
@@ -242,17 +288,35 @@ def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, worker
                          int(hi), n_per_v, False))
     jobs.sort(key=lambda job: -job[0].num_lines*(job[5] - job[4]))
     context = multiprocessing.get_context("spawn")
-    with context.Pool(workers) as pool:
-        pool.map(_cpu_chunk, jobs[-workers:])          # start-up and library load, untimed
+    began = time.perf_counter()
+    pool = context.Pool(workers)
+    try:
+        # start-up and library load, untimed
+        left = None if timeout is None else timeout
+        pool.map_async(_cpu_chunk, jobs[-workers:]).get(left)
+        ready = time.perf_counter()
         start = time.perf_counter()
-        evals = sum(pool.map(_cpu_chunk, jobs, chunksize=1))
+        left = None if timeout is None else max(timeout - (start - began), 1.)
+        evals = sum(pool.map_async(_cpu_chunk, jobs, chunksize=1).get(left))
         seconds = time.perf_counter() - start
+    except multiprocessing.TimeoutError:
+        pool.terminate()
+        pool.join()
+        return {"value": None, "unit": "evals/s", "cores": workers, "kind": "port",
+                "host_cores": os.cpu_count(),
+                "sample": f"given up: {workers} processes not through after {timeout:g} s "
+                          f"(--cpu-pool-timeout)"}
+    pool.close()
+    pool.join()
     return {"value": evals/seconds, "unit": "evals/s", "cores": workers, "kind": "port",
             "host_cores": os.cpu_count(),
+            "usable_hardware_threads": len(os.sched_getaffinity(0)),
+            "pool_start_s": ready - began,
             "sample": f"the grid {v0}-{vn} cm-1 cut into {len(jobs)} (molecule, sub-grid) "
-                      f"units over {workers} processes (--cpu-workers; the pool allots one GPU "
-                      f"16 of the host's {os.cpu_count()} hardware threads), {evals:.4g} evals "
-                      f"in {seconds:.2f} s"}
+                      f"units over {workers} processes ({why or '--cpu-workers'}; the host has "
+                      f"{os.cpu_count()} hardware threads, "
+                      f"{len(os.sched_getaffinity(0))} usable by this process), {evals:.4g} evals "
+                      f"in {seconds:.2f} s (+ {ready - began:.1f} s to start the pool, untimed)"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -286,8 +350,8 @@ def profiled_traffic(workload, kernel="accumulate_kernel"):
 PROFILED_RAW = {}       # kernel -> FETCH_SIZE + WRITE_SIZE as counted (no gfx950 read correction)
 
 
-def profiled_issue(workload):
-    """fp64 VALU wave-instructions per accumulate launch (and busy cycles, when collected) from
+def profiled_issue(workload, kernel="accumulate_kernel"):
+    """fp64 VALU wave-instructions per launch of `kernel` (and busy cycles, when collected) from
     the newest profiles/*_valu_counters.json of this workload (scripts/profile_counters.sh)."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_counters.json")),
@@ -299,19 +363,39 @@ def profiled_issue(workload):
             if summary.get("workload") != workload:
                 continue
             for name, entry in summary["kernels"].items():
-                if "accumulate_kernel" in name:
+                if kernel in name:
                     c = entry["mean_per_launch"]
                     fp64 = sum(c[x] for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
                                               "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"))
                     return {"fp64_wave_instructions_per_launch": fp64,
                             "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                            "salu_wave_instructions_per_launch": c.get("SQ_INSTS_SALU"),
                             "evals_per_launch": summary.get("evals_per_accumulate_launch"),
                             "gui_active_cycles_per_xcd": entry.get("gui_active_cycles_per_xcd"),
                             "sclk_ghz_measured": entry.get("sclk_ghz_from_gui_active"),
+                            "kernel": name,
                             "source": f"profiles/{os.path.basename(path)}"}
         except (OSError, KeyError, TypeError, ValueError):
             continue
     return None
+
+
+def issue_slot_fraction(issue, launch_ms):
+    """Fraction of the chip's fp64 issue slots a launch of `launch_ms` filled: a SIMD issues one
+    fp64 wave-instruction per 4 cycles (16 lanes per cycle), so the ceiling is SIMDS x clock / 4
+    wave-instructions per second -- at the datasheet's 2.4 GHz, and at the clock the profiled
+    launch really ran at (GRBM_GUI_ACTIVE) when that was collected."""
+    if not issue or not launch_ms:
+        return None
+    rate = issue["fp64_wave_instructions_per_launch"]/(launch_ms*1e-3)
+    out = {"fp64_wave_instructions_per_launch": issue["fp64_wave_instructions_per_launch"],
+           "frac_of_issue_slots_at_2.4GHz": rate/(SIMDS*BOOST_CLOCK_GHZ*1e9/4.),
+           "kernel": issue.get("kernel"), "source": issue.get("source")}
+    if issue.get("sclk_ghz_measured"):
+        out["sclk_ghz_measured"] = issue["sclk_ghz_measured"]
+        out["frac_of_issue_slots_at_measured_clock"] = \
+            rate/(SIMDS*issue["sclk_ghz_measured"]*1e9/4.)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -366,6 +450,171 @@ def lines_leg(engine, handles, tables, t, p, vmr, grid_args, steps, remove_pedes
     return {"workload": label, "value": evals*done/elapsed, "unit": "evals/s",
             "ms_per_step": elapsed/done*1e3, "spectra_per_s": levels*done/elapsed,
             "steps": done, "evals_per_step": evals, "remove_pedestal": bool(remove_pedestal)}
+
+
+def alone_roofline(engine, calls, evals_per_step, repeats=2):
+    """The accumulate launches of one step run ALONE -- blocking calls, one lane, nothing beside
+    them -- timed by HIP events on the stream they are launched on (engine option timing = 2):
+    the roofline of a leg whose calls overlap on lanes inside its timed region.
+    calls: [(handle, t, p, x, grid_args, keywords of Engine.compute)].
+    achieved = SURVEY 8(d)'s 7 algorithmic flops per eval x the step's evals / the summed
+    duration of the step's accumulate launches."""
+    from pylbl_amd.engine import DeviceSpectra
+    engine.synchronize()
+    scratch = {}
+    for handle, t, p, x, grid_args, keywords in calls:
+        shape = (len(t), (grid_args[1] - grid_args[0])*grid_args[2])
+        if shape not in scratch:
+            scratch[shape] = DeviceSpectra(engine, *shape)
+    engine.set_option("timing", 2)
+    engine.timing(reset=True)
+    for _ in range(repeats):
+        for handle, t, p, x, grid_args, keywords in calls:
+            shape = (len(t), (grid_args[1] - grid_args[0])*grid_args[2])
+            engine.compute(handle, t, p, x, *grid_args, out=scratch[shape], **keywords)
+    ms, launches = engine.timing(reset=True)
+    engine.set_option("timing", 0)
+    for block in scratch.values():
+        block.free()
+    per_step_ms = ms[2]/repeats
+    tflops = evals_per_step*FLOPS_PER_EVAL/(per_step_ms*1e-3)/1e12
+    return {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops/FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+            "kernel": "lbl::accumulate_kernel", "accumulate_ms_per_step_alone": per_step_ms,
+            "avg_launch_ms": ms[2]/max(launches[2], 1), "launches_timed": launches[2],
+            "farfield_series_ms_per_step_alone": ms[1]/repeats,
+            "flops_per_eval": FLOPS_PER_EVAL,
+            "note": "launches timed alone (blocking calls on one lane, HIP events on the "
+                    "engine's stream), after the leg's timed region"}
+
+
+def share_leg(engine, name, tables, handles, level_indices, levels_total, grid_args, output,
+              steps, label, remove_pedestal=True, farfield=False):
+    """One GPU's share of a multi-GPU BASELINE config, through the code the N-GPU job runs
+    (pylbl_amd.distributed.ShardedLines.for_engine): the given levels of the build-owned standard
+    atmosphere x every molecule of the config, spectra (output "gas") or their n k sum over the
+    gases (output "total") left in torch-owned HBM.  Wall clock around `steps` asynchronous runs;
+    roofline from the same launches timed alone."""
+    from pylbl_amd import distributed, synthetic
+    atmos = synthetic.standard_atmosphere(levels_total)
+    t, p = atmos.t[level_indices], atmos.p[level_indices]
+    vmr = {table.formula: atmos.vmr[table.formula][level_indices] for table in tables}
+    by_formula = {table.formula: handles[i] for i, table in enumerate(tables)}
+    sharded = distributed.ShardedLines.for_engine(
+        engine, by_formula, grid_args, remove_pedestal=remove_pedestal,
+        scale_density=(output == "total"), weights=[table.num_lines for table in tables],
+        farfield=farfield)
+    from pylbl_amd.engine import DeviceSpectra
+    n = (grid_args[1] - grid_args[0])*grid_args[2]
+    evals = 0
+    scratch = DeviceSpectra(engine, len(t), n)
+    for table in tables:
+        _, count = engine.compute(by_formula[table.formula], t, p, vmr[table.formula], *grid_args,
+                                  remove_pedestal=remove_pedestal, want_evals=True,
+                                  farfield=farfield, out=scratch)
+        evals += count
+    scratch.free()
+    pending = []
+    for _ in range(2):          # every lane's workspace and both sets of blocks used once
+        pending.append(sharded.run(t, p, vmr, output=output, async_op=True))
+    for item in pending:
+        item.wait()
+    engine.synchronize()
+    start = time.perf_counter()
+    pending = [sharded.run(t, p, vmr, output=output, async_op=True) for _ in range(steps)]
+    for item in pending:
+        item.wait()
+    engine.synchronize()
+    elapsed = time.perf_counter() - start
+    calls = [(by_formula[table.formula], t, p, vmr[table.formula], grid_args,
+              {"remove_pedestal": remove_pedestal, "farfield": farfield}) for table in tables]
+    roofline = alone_roofline(engine, calls, evals, repeats=1)
+    if farfield:
+        roofline["frac"] = None
+    del sharded
+    return {"workload": label, "value": evals*steps/elapsed, "unit": "evals/s",
+            "ms_per_step": elapsed/steps*1e3, "spectra_per_s": len(level_indices)*steps/elapsed,
+            "steps": steps, "evals_per_step": evals, "remove_pedestal": bool(remove_pedestal),
+            "levels": [int(x) for x in level_indices], "levels_of_the_config": levels_total,
+            "molecules": [table.formula for table in tables], "points": n, "output": output,
+            "hbm_output_bytes": (1 if output == "total" else len(tables))*len(level_indices)*n*8,
+            "through": "pylbl_amd.distributed.ShardedLines.for_engine (world 1)",
+            "roofline": roofline}
+
+
+def ingest_leg(engine, tables, db_path, atmos, grid_args):
+    """What it costs to get a molecule's line table from the reference's SQLite file into HBM
+    (line-table load time reported separately; the reference pays its read
+    on every call, absorption.c:44-86): the three routes of pylbl_amd.database.line_table_of,
+    the upload (lbl_molecule_load: sort by wavenumber, eleven arrays to HBM), and the
+    same-signature C entry's first call on a file (SQLite read in C + upload + compute) against
+    its second (line table found resident)."""
+    from ctypes import c_char_p, c_double, c_int32
+    from pylbl_amd import database
+    out = {"database": f"SQLite file in the reference's schema, "
+                       f"{'+'.join(f'{t.formula} {t.num_lines}' for t in tables)} transitions",
+           "routes": {}, "per_molecule": {}}
+
+    class PathOnly(object):             # what pyLBL.database.Database looks like from outside
+        def __init__(self, path):
+            self.path = path
+
+    class QueriesOnly(object):          # a database object that cannot be opened as a file
+        def __init__(self, inner):
+            self.gas, self.tips = inner.gas, inner.tips
+    file_backed = database.Database(db_path)
+    routes = (("line_table", "an object with line_table(name) (this package's Database)",
+               file_backed),
+              ("path", "an object with .path only (pyLBL.database.Database as the reference hands "
+                       "it over, spectroscopy.py:54): the C engine's own four SELECTs", PathOnly(db_path)),
+              ("gas_tips", "an object with .gas(name) / .tips(name) only (record arrays; the "
+                           "reference's ORM rows would add their own object construction)",
+               QueriesOnly(file_backed)))
+    loaded = {}
+    for key, what, source in routes:
+        seconds = {}
+        for table in tables:
+            start = time.perf_counter()
+            loaded[table.formula] = database.line_table_of(source, table.formula)
+            seconds[table.formula] = time.perf_counter() - start
+        out["routes"][key] = {"what": what, "seconds": seconds, "total_s": sum(seconds.values())}
+    upload = {}
+    for table in tables:
+        start = time.perf_counter()
+        handle = engine.load(loaded[table.formula])
+        upload[table.formula] = time.perf_counter() - start
+        engine.free(handle)
+    out["upload_s"] = upload
+    # The drop-in C entry (absorption.c:19-30's signature): first call reads the file itself.
+    lib = engine.lib
+    v0, vn, n_per_v = grid_args
+    k = np.zeros((vn - v0)*n_per_v)
+    first, second = {}, {}
+    for table in tables:
+        args = (c_double(atmos.p[0]), c_double(atmos.t[0]), c_double(atmos.vmr[table.formula][0]),
+                c_int32(v0), c_int32(vn), c_int32(n_per_v), k.ctypes.data,
+                c_char_p(str(db_path).encode()), c_char_p(table.formula.encode()), c_int32(25),
+                c_int32(0))
+        for book in (first, second):
+            start = time.perf_counter()
+            status = lib.lbl_absorption(*args)
+            book[table.formula] = time.perf_counter() - start
+            if status != 0:
+                raise RuntimeError("lbl_absorption failed")
+    out["c_entry_first_call_s"] = first
+    out["c_entry_second_call_s"] = second
+    for table in tables:
+        f = table.formula
+        out["per_molecule"][f] = {
+            "lines": int(table.num_lines),
+            "read_s": out["routes"]["path"]["seconds"][f], "upload_s": upload[f],
+            "c_entry_ingest_s": first[f] - second[f]}
+    out["note"] = ("paid once per molecule and process (resident line tables; the C entry keys "
+                   "them by path + mtime + inode); compare cpu_baseline.split."
+                   "read_s_per_molecule, which the reference pays on every (level, molecule) call. "
+                   "c_entry_*: host array in and out, so both calls include the 40 MB-class "
+                   "copy back; their difference is the ingest")
+    return out
 
 
 def api_leg(engine, tables, atmos, v_lo, v_hi, dv, device_step_ms, repeats=9):
@@ -589,6 +838,15 @@ def cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, steps, with_cpu):
     }
 
 
+def rccl_libraries():
+    """File names of the RCCL libraries mapped into this process (empty: RCCL never loaded)."""
+    try:
+        with open("/proc/self/maps") as handle:
+            return sorted({text.split("/")[-1].strip() for text in handle if "rccl" in text})
+    except OSError:
+        return []
+
+
 def device_identity(torch, index):
     """What tells two GPUs apart: name, UUID and PCI address of HIP device `index` (each only
     where this torch exposes it)."""
@@ -770,8 +1028,21 @@ def run():
     torch.cuda.set_device(device_index)
     identity = dict(device_identity(torch, device_index), rank=rank, local_rank=local_rank,
                     host=os.uname().nodename, pid=os.getpid())
-    if world > 1:
+    # --force-group: the process group (and with nccl: RCCL, a communicator, its streams) also
+    # for ONE rank -- what a one-GPU box can rehearse of the N-GPU run before the first lease
+    # of a whole node.
+    grouped = world > 1 or args.force_group
+    if grouped:
         from datetime import timedelta
+        if world == 1:
+            import socket
+            with socket.socket() as probe:
+                probe.bind(("127.0.0.1", 0))
+                free_port = probe.getsockname()[1]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("PYLBL_AMD_EXCHANGE_TIMEOUT", str(args.exchange_timeout))
         limit = timedelta(seconds=max(args.exchange_timeout, 30.))
         if args.backend == "nccl":
@@ -842,7 +1113,8 @@ def run():
     # written by the engine into torch-owned HBM, one grouped send/recv to rank 0 per step.
     sharded = distributed.ShardedLines.for_engine(
         engine, handles, grid_args, remove_pedestal=args.pedestal,
-        scale_density=(args.output == "total"), weights=[t.num_lines for t in tables])
+        scale_density=(args.output == "total"), weights=[t.num_lines for t in tables],
+        always_exchange=args.force_group)
     vmr = {f: atmos.vmr[f] for f in molecules}
     plan = distributed.partition(levels_total, [t.num_lines for t in tables], world)
     host_spectra = engine.host_array((len(molecules), levels_local, n)) if args.host_output \
@@ -864,9 +1136,11 @@ def run():
     def step():
         which = counter[0] % 2
         counter[0] += 1
-        if world > 1 and pending[which] is not None:
-            # The exchange that last read this pair of buffers.  (One rank: the engine's own
-            # streams order successive writes to a buffer, nothing to wait for.)
+        if grouped and pending[which] is not None:
+            # The exchange that last used this pair of buffers: settled here so that its bytes
+            # and seconds are booked (ShardedLines itself orders a buffer's next writer behind
+            # the exchange that last used it).  (One rank, no group: the engine's own streams
+            # order successive writes to a buffer, nothing to wait for.)
             settle(which)
         if args.host_output:
             for m, formula in enumerate(molecules):
@@ -895,7 +1169,7 @@ def run():
             if pending[which] is not None:
                 settle(which)
         engine.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -924,7 +1198,7 @@ def run():
     engine.set_option("timing", 0)
 
     per_rank = None
-    if world > 1 and not args.host_output:
+    if grouped and not args.host_output:
         # The exchange by itself, once, outside the timed region: kernels first (host waits),
         # then the collection alone -- what a step would pay if nothing overlapped it.
         fence()
@@ -952,8 +1226,8 @@ def run():
     # (One rank: nothing to reduce, and no torch kernel or copy is put on the GPU for it -- the
     # first one a process launches makes every later call of the engine ~0.5 ms slower)
     stats = torch.tensor([elapsed, float(evals_per_step_local)], dtype=torch.float64,
-                         device="cpu" if (world == 1 or args.backend == "gloo") else "cuda")
-    if world > 1:
+                         device="cpu" if (not grouped or args.backend == "gloo") else "cuda")
+    if grouped:
         worst = stats.clone()
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         total = stats.clone()
@@ -991,7 +1265,7 @@ def run():
                 + (f", one grouped {args.backend} send/recv to rank 0 per step, overlapping the "
                    f"next step" if world > 1 else ""),
             },
-            "distributed": None if world == 1 else {
+            "distributed": None if not grouped else {
                 "world_size": dist.get_world_size(), "backend": dist.get_backend(),
                 "launcher": os.environ.get("PYLBL_BENCH_LAUNCHER") or (
                     "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
@@ -1003,6 +1277,7 @@ def run():
                                                 "the exchange's, no host wait)"
                 if (args.backend == "nccl" or sharded.order_on_device) else "host (synchronize)",
                 "exchange_timeout_s": args.exchange_timeout,
+                "rccl_mapped": rccl_libraries(),
                 "bytes_to_rank0_per_step": (per_rank or [{}])[0].get("bytes_received_per_step"),
                 "exchange_alone_ms_max": max((r["unoverlapped_exchange_ms"]
                                               for r in per_rank), default=None)
@@ -1110,7 +1385,8 @@ def run():
             line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
 
     # ---- untimed legs, one GPU only -----------------------------------------------------------
-    plain = world == 1 and not args.ablate and not args.host_output
+    plain = world == 1 and not args.force_group and not args.ablate and not args.host_output
+    shared_db = None
     if plain and rank == 0 and args.extras != "none":
         handle_list = [handles[f] for f in molecules]
         t1, p1 = atmos.t[:1], atmos.p[:1]
@@ -1169,14 +1445,14 @@ def run():
             dense_handles = [engine.load(t) for t in dense]
             dense_vmr = {"CO2": atmos.vmr["CO2"][:1]} if "CO2" in atmos.vmr else \
                 {"CO2": np.asarray([3.6e-4])}
-            plain = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
+            dense_plain = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
                               max(args.steps//2, 2), remove_pedestal=False, ring=2,
                               label="one molecule, 1.6 M lines in 8 Gaussian bands inside the grid "
                                     "(synthetic.banded_line_table(inside=True))")
             with_pedestal = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
                                       max(args.steps//2, 2), remove_pedestal=True, ring=2,
                                       label="the same with remove_pedestal=True")
-            line["dense_table_option"] = {"plain": plain, "remove_pedestal": with_pedestal,
+            line["dense_table_option"] = {"plain": dense_plain, "remove_pedestal": with_pedestal,
                                           "lines": int(dense[0].num_lines)}
             for h in dense_handles:
                 engine.free(h)
@@ -1200,16 +1476,131 @@ def run():
             engine.set_option("farfield", 1)
             far = {}
             for ped in (False, True):
-                far["remove_pedestal" if ped else "plain"] = lines_leg(
+                key = "remove_pedestal" if ped else "plain"
+                far[key] = lines_leg(
                     engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
                     remove_pedestal=ped)
+                # What the series leaves to be executed point by point is no longer "7 flops x the
+                # closed-form evals": the fraction is the share of the chip's fp64 ISSUE SLOTS the
+                # launch filled -- executed fp64 wave-instructions (PMC pass of this same
+                # workload, profiles/) over the launch's duration here, timed alone.
+                calls = [(h, t1, p1, vmr1[tb.formula], grid_args, {"remove_pedestal": ped})
+                         for h, tb in zip(handle_list, tables)]
+                alone = alone_roofline(engine, calls, far[key]["evals_per_step"], repeats=3)
+                far_workload = workload.replace(
+                    "remove_pedestal=False", f"remove_pedestal={ped}") + ", far-field series on"
+                roof = {"bound": "valu_fp64_issue", "unit": "fraction of fp64 issue slots",
+                        "kernel": "lbl::accumulate_kernel<8>",
+                        "avg_launch_ms": alone["avg_launch_ms"],
+                        "accumulate_ms_per_step_alone": alone["accumulate_ms_per_step_alone"],
+                        "farfield_series_ms_per_step_alone":
+                            alone["farfield_series_ms_per_step_alone"],
+                        "launches_timed": alone["launches_timed"], "frac": None, "traffic": None}
+                issue = issue_slot_fraction(profiled_issue(far_workload), alone["avg_launch_ms"])
+                if issue is not None:
+                    roof["issue"] = issue
+                    roof["frac"] = issue.get("frac_of_issue_slots_at_measured_clock",
+                                             issue["frac_of_issue_slots_at_2.4GHz"])
+                    roof["achieved"], roof["peak"] = roof["frac"], 1.0
+                for kernel in ("farfield_kernel", "farfield_group_kernel"):
+                    counted, source = profiled_traffic(far_workload, kernel)
+                    if counted is not None:
+                        roof.setdefault("series_kernels", {})[kernel] = {
+                            "hbm_bytes_per_launch": counted, "source": f"profiles/{source}"}
+                if "series_kernels" in roof and alone["farfield_series_ms_per_step_alone"] > 0.:
+                    moved = sum(v["hbm_bytes_per_launch"] for v in roof["series_kernels"].values())
+                    # (one launch of each per molecule call)
+                    seconds = alone["farfield_series_ms_per_step_alone"]*1e-3/len(handle_list)
+                    roof["series_kernels"]["hbm"] = {
+                        "bound": "hbm", "achieved": moved/seconds/1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": moved/seconds/1e9/HBM_PEAK_GBS,
+                        "note": "HBM bytes of the two series kernels (PMC) / their duration here"}
+                roof["note"] = (
+                    "far-field series on: frac = executed fp64 wave-instructions per "
+                    "accumulate_kernel<8> launch (rocprofv3 --pmc pass of this workload, "
+                    "profiles/) x 4 cycles / (1024 SIMDs x shader clock x launch duration, HIP "
+                    "events, launches run alone); None until a counter summary of this exact "
+                    "workload is committed")
+                far[key]["roofline"] = roof
             engine.set_option("farfield", 0)
             far["note"] = ("engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 "
                            "tile half-widths away are summed as one power series per tile "
                            "(truncation <= ~1.5e-11 relative); same closed-form eval count; "
                            "parity-tested at the same 1e-6 bar; what Spectroscopy(farfield=True) "
-                           "runs; never the headline value")
+                           "runs -- remove_pedestal is what a user of compute_absorption() gets "
+                           "by default (spectroscopy.py:163-164); never the headline value")
             line["farfield_option"] = far
+        if (leg("ingest") or (not args.no_cpu_baseline)) and args.config == "target":
+            # One SQLite file in the reference's schema for the ingest leg and the CPU baseline.
+            import tempfile
+            from pylbl_amd.database import write_database
+            shared_tmp = tempfile.TemporaryDirectory()
+            begin = time.perf_counter()
+            shared_db = write_database(os.path.join(shared_tmp.name, "lines.db"), tables)
+            db_written_s = time.perf_counter() - begin
+        if leg("ingest") and shared_db is not None:
+            line["ingest"] = ingest_leg(engine, tables, shared_db, atmos, grid_args)
+            line["ingest"]["fixture_written_in_s"] = db_written_s
+        if args.config == "target" and (leg("config2") or leg("config4")):
+            # The other BASELINE configs at one GPU's size (the eight README molecules on
+            # 1-5000 cm-1 serve configs[2] and configs[4]).
+            eight = [t for t in tables if t.formula in EIGHT]
+            have = {t.formula for t in eight}
+            eight += [synthetic.line_table(f, 1., 5000., scale=args.line_scale)
+                      for f in EIGHT if f not in have]
+            eight.sort(key=lambda t: EIGHT.index(t.formula))
+            eight_handles = [handles[t.formula] if t.formula in handles else engine.load(t)
+                             for t in eight]
+            if leg("config2"):
+                surface = synthetic.surface_level()
+                vmr8 = {f: surface.vmr[f][:1] for f in EIGHT}
+                entry = lines_leg(
+                    engine, eight_handles, eight, t1, p1, vmr8, grid_args, max(args.steps//2, 3),
+                    remove_pedestal=False,
+                    label="BASELINE configs[2]: 1 level, all 8 README molecules "
+                          f"({'+'.join(EIGHT)}), 1-5000 cm-1 at 0.001 cm-1 (5 M points), "
+                          "remove_pedestal=False like the headline")
+                calls = [(h, t1, p1, vmr8[tb.formula], grid_args, {"remove_pedestal": False})
+                         for h, tb in zip(eight_handles, eight)]
+                entry["roofline"] = alone_roofline(engine, calls, entry["evals_per_step"])
+                entry["lines"] = {t.formula: int(t.num_lines) for t in eight}
+                line["config2_option"] = entry
+            if leg("config4"):
+                ga4 = synthetic.grid_arguments(np.asarray([1., 1.0005, 5000. - 0.0005]))
+                rank3 = distributed.level_shard(256, 3, 8)
+                picked = list(range(rank3.start, rank3.stop, 8))        # 96, 104, 112, 120
+                line["config4_share_option"] = share_leg(
+                    engine, "4", eight, eight_handles, picked, 256, ga4, "total",
+                    max(args.steps//6, 3),
+                    label="BASELINE configs[4] (256 levels x 8 molecules, 1-5000 cm-1 at 0.0005 "
+                          "cm-1 = 10 M points, over 8 GPUs): 4 of rank 3's 32 levels "
+                          f"(levels {picked} of the 256-level standard atmosphere) x 8 molecules, "
+                          "remove_pedestal=True, n k summed over the gases on the device "
+                          "(output 'total')")
+            for t, h in zip(eight, eight_handles):
+                if t.formula not in handles:
+                    engine.free(h)
+        if args.config == "target" and leg("config3"):
+            mols3, lo3, hi3, dv3, levels3 = CONFIGS["3"]
+            ga3 = synthetic.grid_arguments(np.asarray([lo3, lo3 + dv3, hi3 - dv3]))
+            tables3 = [synthetic.line_table(f, lo3, hi3, scale=args.line_scale) for f in mols3]
+            handles3 = [engine.load(t) for t in tables3]
+            shares = {}
+            for share_rank in (0, 7):
+                block = distributed.level_shard(levels3, share_rank, 8)
+                picked = list(range(block.start, block.stop))
+                shares[share_rank] = share_leg(
+                    engine, "3", tables3, handles3, picked, levels3, ga3, "gas",
+                    max(args.steps//6, 3),
+                    label=f"BASELINE configs[3] (64-level standard atmosphere, {'+'.join(mols3)}, "
+                          f"1-3000 cm-1 at 0.001 cm-1 = 3 M points, levels sharded over 8 GPUs): "
+                          f"rank {share_rank}'s share, levels {picked[0]}-{picked[-1]} "
+                          f"({'1013-330 hPa' if share_rank == 0 else '0.3-0.1 hPa: the slowest share, it bounds the job'}), "
+                          "remove_pedestal=True, one spectrum per gas left in HBM")
+            # The share that bounds the 8-GPU job is the record's entry; rank 0's rides along.
+            line["config3_share_option"] = dict(shares[7], rank0_share=shares[0])
+            for h in handles3:
+                engine.free(h)
         if leg("api"):
             # What the call queues on the device: Spectroscopy sums distant lines through the
             # far-field series by default and removes the pedestal (continua on).
@@ -1235,15 +1626,33 @@ def run():
                 extra["roofline"]["traffic"] = traffic
                 extra["roofline"]["traffic_source"] = f"profiles/{source}"
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.extras != "none":
+        if plain and not args.no_cpu_baseline and args.extras != "none":
+            db = shared_db
             line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, grid_vn, n_per_v,
-                                                args.cpu_sample_cm, args.pedestal)
+                                                args.cpu_sample_cm, args.pedestal, db=db)
             workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
             if workers > 1:
                 line["cpu_baseline_parallel"] = cpu_baseline_parallel(
                     tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
+            usable = len(os.sched_getaffinity(0))
+            every = usable if args.cpu_all_cores < 0 else min(args.cpu_all_cores, usable)
+            if every > workers:
+                line["cpu_baseline_all_cores"] = cpu_baseline_parallel(
+                    tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, every,
+                    timeout=args.cpu_pool_timeout,
+                    why="--cpu-all-cores: every hardware thread this process may run on")
+        line["environment"] = {
+            "variables": {k: v for k, v in sorted(os.environ.items())
+                          if k.startswith("PYLBL_AMD_") or k in ("LBL_DEVICE", "LBL_COMPAT_CACHE",
+                                                                 "PYLBL_MT_CKD", "PYLBL_FUZZ_CASES")},
+            "engine_options_from_environment": dict(engine.environment_options),
+            "engine_options_from_command_line": list(args.engine_option),
+            "note": "every PYLBL_AMD_* variable in effect: PYLBL_AMD_OPTIONS changes engine "
+                    "options for every engine of the process ('ablate' is refused there)"}
+        if engine.environment_options:
+            line["non_default_engine_options"] = dict(engine.environment_options)
         print(json.dumps(line), file=result_stream, flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     engine.close()

@@ -147,8 +147,11 @@ int lbl_deferred(const lbl_engine *engine);
 /* Drops what a call kept back instead of queueing it: the call's target block and host range
  * are then never written by it (what it queued before works in buffers of the engine).  For
  * hosts that fail between a deferred call and its lbl_finish_deferred and are about to release
- * the block.  lbl_device_free, lbl_host_free, lbl_copy_to_host, lbl_copy_rows_to_host and
- * lbl_order_stream_after_engine finish a deferred call first (like lbl_synchronize). */
+ * the block.  lbl_copy_to_host, lbl_copy_rows_to_host and lbl_order_stream_after_engine finish a
+ * deferred call first (like lbl_synchronize); lbl_device_free and lbl_host_free do so only when
+ * the memory they release is memory that call still has to write (its output block, the host
+ * range of its delivery) -- a free of anything else, from whichever thread, leaves the deferral
+ * and with it the order of a pipeline's additions alone. */
 int lbl_cancel_deferred(lbl_engine *engine);
 
 /* Waits for everything enqueued on the engine (all of its streams); a deferred call is finished
@@ -162,8 +165,9 @@ int lbl_synchronize(lbl_engine *engine);
 int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
                   int64_t level_stride, int32_t flags);
 
-/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1:
- * record HIP events around every kernel), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
+/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1/2:
+ * record HIP events around every kernel; 2 = only around the accumulate and far-field series
+ * launches, so that the others keep running back to back), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
  * pre-pass on a side stream, default 1), "scan_chain" (0/1: the pedestal recurrence by
  * relaxation where it applies, the serial chain behind it; default 1), "relax_launches" (0, 2..7:
  * relaxation launches before the serial chain takes what has not settled; 0 = three, or five for
@@ -177,8 +181,10 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
  * graph of their kernels; default 0), "ablate" (timing diagnostics only). */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
-/* With option timing=1: accumulated kernel milliseconds and launch counts since the last
- * reset; index 0 line-scalar prep, 1 tile schedule, 2 Voigt accumulate, 3 pedestal,
+/* With option timing=1 (or 2): accumulated kernel milliseconds and launch counts since the last
+ * reset; index 0 line-scalar prep (+ tile schedule: one prologue launch), 1 the far-field
+ * series kernels (and the tile schedule when it is launched alone, LBL_PREP_HOST), 2 Voigt
+ * accumulate (+ combine), 3 pedestal,
  * 4 continuum band spectra, 5 continuum interpolation, 6 cross-section fit, 7 cross-section
  * interpolation.  Synchronizes the streams. */
 int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t reset);

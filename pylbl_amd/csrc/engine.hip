@@ -354,6 +354,8 @@ int lbl_synchronize(lbl_engine * engine)
 int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
 {
     if (engine == nullptr || name == nullptr) return LBL_BAD_ARGUMENT;
+    // (compute() reads the options under the same lock: none changes in the middle of a call)
+    EngineLock lock(engine->mutex);
     const std::string key(name);
     if (key == "prep" && (value == LBL_PREP_DEVICE || value == LBL_PREP_HOST))
     {

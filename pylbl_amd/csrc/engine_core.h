@@ -114,6 +114,8 @@ struct Molecule
     }
 };
 
+// (kTimeSchedule: schedule_kernel alone, which only host-side prep launches; the far-field series
+// kernels are booked there too -- with device prep the index would otherwise stay empty)
 enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal = 3,
        kTimeBandSpectra = 4, kTimeContinuum = 5, kTimeXsecModel = 6, kTimeXsec = 7,
        kTimeKinds = 8 };
@@ -434,7 +436,7 @@ struct lbl_engine
     template <typename F>
     void timed(int kind, hipStream_t on, F && launch, int counts = 1)
     {
-        if (!timing || (timing == 2 && kind != kTimeAccumulate))
+        if (!timing || (timing == 2 && kind != kTimeAccumulate && kind != kTimeSchedule))
         {
             launch();
             return;
@@ -494,6 +496,43 @@ struct lbl_engine
     }
 
     Lane * deferred = nullptr;      // the lane whose call waits for lbl_finish_deferred
+
+    // Memory handed out by lbl_device_alloc / lbl_host_alloc: base address and size, so that a
+    // free knows whether a call kept back (LBL_DEFER_FINISH) still has that memory to write.
+    struct Block { const char * begin; long long bytes; };
+    std::vector<Block> device_blocks, host_blocks;
+
+    static long long forget(std::vector<Block> & blocks, const void * pointer)
+    {
+        for (size_t i = 0; i < blocks.size(); ++i)
+        {
+            if (blocks[i].begin == pointer)
+            {
+                const long long bytes = blocks[i].bytes;
+                blocks.erase(blocks.begin() + i);
+                return bytes;
+            }
+        }
+        return -1;      // not one of ours (or freed twice): the caller assumes the worst
+    }
+
+    // Does the call kept back write into [begin, begin + bytes)?  bytes < 0: size unknown, yes.
+    bool deferred_touches(const void * begin, long long bytes) const
+    {
+        if (deferred == nullptr || !deferred->finish.pending) return false;
+        if (bytes < 0) return true;
+        const Lane::Finish & f = deferred->finish;
+        const char * b = reinterpret_cast<const char *>(begin);
+        const char * e = b + bytes;
+        auto meets = [&](const void * p, long long n) {
+            const char * q = reinterpret_cast<const char *>(p);
+            return p != nullptr && n > 0 && q < e && b < q + n;
+        };
+        const long long rows = ((long long)(f.count - 1)*f.target_stride + f.point_begin[f.pieces])*8;
+        return meets(f.k, f.out_bytes) || meets(f.target, rows) ||
+               (f.streamed && meets(f.host + f.base*f.host_pitch,
+                                    (long long)(f.count - 1)*f.host_pitch + f.columns*8));
+    }
 
     // Queues what Lane::Finish describes: apply kernels (+ copies) of every piece, then ties the
     // lane's main stream and the block's write record to the last of them.

@@ -579,9 +579,16 @@ class ShardedLines(object):
                     for key, levels in pieces(sender):
                         if not levels:
                             continue
-                        if sender == rank:
+                        if sender == rank and not (self.always_exchange and backend == "nccl"):
                             place(key, levels).copy_(blocks[key])
                         else:
+                            if sender == rank:
+                                # (always_exchange over RCCL: this rank's own blocks travel by
+                                # a send to itself inside the same group of operations -- the
+                                # code and the library a block from another GPU goes through)
+                                ops.append(dist.P2POp(dist.isend, blocks[key],
+                                                      _global_rank(self.group, rank), self.group))
+                                sent += sizes[key]
                             target = place(key, levels)
                             ops.append(dist.P2POp(dist.irecv, target,
                                                   _global_rank(self.group, sender), self.group))

@@ -328,9 +328,20 @@ class Engine(object):
         # the C ABI serialises them per handle (include/lbl_amd.h, "Threads").
         self.pipeline = threading.RLock()
         # Options for every engine of the process, for experiments: PYLBL_AMD_OPTIONS="name=value,..."
+        # (kept in `environment_options` so that whoever reports numbers can say so: bench.py
+        # echoes them).  "ablate" leaves work out -- results are wrong -- and is refused here: a
+        # left-over environment variable must not change what every Gas object returns.
+        self.environment_options = {}
         for pair in filter(None, os.environ.get("PYLBL_AMD_OPTIONS", "").split(",")):
             name, _, value = pair.partition("=")
-            self.set_option(name.strip(), float(value))
+            name = name.strip()
+            if name == "ablate":
+                self.close()
+                raise EngineError("PYLBL_AMD_OPTIONS must not set 'ablate' (results would be "
+                                  "wrong for every engine of the process); use "
+                                  "Engine.set_option('ablate', ...) on the one engine being timed.")
+            self.set_option(name, float(value))
+            self.environment_options[name] = float(value)
 
     def host_array(self, shape):
         """float64 array of the given shape in page-locked host memory (recycled, see
@@ -606,9 +617,9 @@ class Engine(object):
         return np.split(spectra, np.cumsum(sizes)[:-1])
 
     def timing(self, reset=False):
-        """(milliseconds[8], launches[8]) for prepare, schedule, accumulate, pedestal,
-        continuum band spectra, continuum interpolation, cross-section fit, cross-section
-        interpolation."""
+        """(milliseconds[8], launches[8]) for prepare (prologue), far-field series (and the tile
+        schedule of host-side prep), accumulate, pedestal, continuum band spectra, continuum
+        interpolation, cross-section fit, cross-section interpolation."""
         ms = (c_double*8)()
         launches = (c_int64*8)()
         self._check(self.lib.lbl_timing(self.handle, ms, launches, 1 if reset else 0))

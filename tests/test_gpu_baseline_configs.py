@@ -41,6 +41,14 @@ allowance for the pedestal, see test_gpu_zz_tolerance_report.py):
   end to end  Spectroscopy.compute_absorption() with default arguments at 5 M points, one
               level, H2O + CO2 + a cross-section-only gas: the three mechanism slots against the
               three oracles.
+  default path at the big shapes (round 5)  what Spectroscopy runs by default -- far-field
+              series AND pedestal removed -- at every point of configs[4]'s grid (n_per_v = 2000,
+              10 M points) for H2O / CO2 / O3 at levels 170 (~1 hPa) and 255 (0.1 hPa); through
+              ShardedLines.for_engine(farfield=True) for rank 0's and rank 7's blocks of
+              configs[3] (levels 0 and 63 at all 3 M points) and rank 5's share of configs[4]
+              (32 levels x 8 molecules summed on the device, level 170 at all 10 M points); and
+              the CO2 table at 5 M points with cut_off 5 and 40 (spectra.c:48-62 with another
+              window, voigt.c:17-27,79-83), pedestal off and on, direct and far-field.
 """
 import warnings
 
@@ -66,6 +74,7 @@ FULL_LEVEL = 170
 BANDED = ("banded", "CO2", 1., 5000., 300_000, 8, 41)
 HITRAN_SHAPED = ("hitran", 1.e-4, 5026., 150_000, 8101)
 HITRAN_LEVEL = (250., 5.e4, 4.e-4)
+OTHER_CUTS = (5, 40)
 
 
 def uniform(formula, v_lo=1., v_hi=5000.):
@@ -116,6 +125,17 @@ def farm():
         for ped in (False, True):
             f.submit(("c4", formula, FULL_LEVEL, ped), uniform(formula), t, p, x, 1, 5001, 2000,
                      ped)
+    # the default user path at configs[4]'s top level too (H2O / CO2 / O3; CO / O2 / N2 above)
+    for formula in ("H2O", "CO2", "O3"):
+        t, p, x = level_of(STANDARD256, formula, LEVELS256[-1])
+        for ped in (False, True):
+            f.submit(("c4", formula, LEVELS256[-1], ped), uniform(formula), t, p, x, 1, 5001,
+                     2000, ped)
+    # other cut-offs than the 25 every caller of the reference gets (gas_optics.py:46-47)
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    for cut in OTHER_CUTS:
+        for ped in (False, True):
+            f.submit(("cut", cut, ped), uniform("CO2"), t, p, x, 1, 5001, 1000, ped, cut=cut)
     # banded table, pedestal on (+ the plain spectrum its tolerance refers to)
     t, p, x = level_of(SURFACE, "CO2", 0)
     for ped in (False, True):
@@ -136,16 +156,16 @@ def engine():
     e.close()
 
 
-def case_for(v0, vn, npv, ped, index=0):
-    return golden_io.Case("baseline", index, 0, 0, 0, v0, vn, npv, 25, ped, None, 0)
+def case_for(v0, vn, npv, ped, index=0, cut=25):
+    return golden_io.Case("baseline", index, 0, 0, 0, v0, vn, npv, cut, ped, None, 0)
 
 
-def check_full(farm, key_plain, key, k, v0, vn, npv, ped, label, evals=None):
+def check_full(farm, key_plain, key, k, v0, vn, npv, ped, label, evals=None, cut=25):
     k_ref, evals_ref = farm.result(key)
     if evals is not None:
         assert evals == evals_ref, f"{label}: eval count {evals} != oracle {evals_ref}"
     k_plain = farm.result(key_plain)[0] if ped else None
-    assert_spectrum(k, k_ref, case_for(v0, vn, npv, ped), f"baseline {label}", k_plain)
+    assert_spectrum(k, k_ref, case_for(v0, vn, npv, ped, cut=cut), f"baseline {label}", k_plain)
 
 
 def check_windows(oracle, table, k, t, p, x, v0, vn, npv, starts, label, width=2):
@@ -319,8 +339,10 @@ def test_config4_one_gpus_share_through_the_sharded_path(engine, oracle):
         engine.free(handle)
 
 
-def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine):
-    """The same call the way Spectroscopy.compute_absorption makes it by default
+@pytest.mark.parametrize("farfield", [False, True])
+def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine, farfield):
+    """(farfield=True: with the far-field series too, Spectroscopy's other default.)
+    The same call the way Spectroscopy.compute_absorption makes it by default
     (spectroscopy.py:163-164: the pedestal is removed when the continuum is MT-CKD): rank 5's
     block of the 8-GPU job (levels 160..191 x 8 molecules x 10 M points), n k summed over the
     gases on the device with remove_pedestal=True -- every call but the first goes through the
@@ -340,7 +362,7 @@ def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine):
     handles = {f: engine.load(tables[f]) for f in formulas}
     sharded = distributed.ShardedLines.for_engine(
         engine, handles, (1, 5001, 2000), remove_pedestal=True, scale_density=True,
-        weights=[tables[f].num_lines for f in formulas])
+        weights=[tables[f].num_lines for f in formulas], farfield=farfield)
     total = sharded.run(t, p, vmr, output="total")
     assert tuple(total.shape) == (32, 10_000_000)
     row = FULL_LEVEL - mine.start
@@ -357,7 +379,8 @@ def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine):
         tol = np.maximum(tol, golden_io.pedestal_tolerance(k_plain, 2000, 25, 1.e-13))
         tolerance += density*tol
     worst = float(np.max(np.abs(got - expect)/(tolerance + 1e-300)))
-    assert worst <= 1., f"baseline config4 share with pedestal, level {FULL_LEVEL}: {worst:.3g} x"
+    assert worst <= 1., (f"baseline config4 share with pedestal, farfield={farfield}, level "
+                         f"{FULL_LEVEL}: {worst:.3g} x")
     # The other rows: finite, and the neighbours of level 170 differ from it (every level its own).
     for other in (row - 1, row + 1, 0, 31):
         values = total[other, ::1000].cpu().numpy()
@@ -366,8 +389,10 @@ def test_config4_one_gpus_share_with_the_pedestal_removed(farm, engine):
         engine.free(handle)
 
 
-def test_config3_blocks_of_the_64_level_job(farm, engine):
-    """configs[3] as the 8-GPU job cuts it: 64 standard-atmosphere levels, H2O + CO2 + O3,
+@pytest.mark.parametrize("farfield", [False, True])
+def test_config3_blocks_of_the_64_level_job(farm, engine, farfield):
+    """(farfield=True: the series on, as Spectroscopy runs it by default.)
+    configs[3] as the 8-GPU job cuts it: 64 standard-atmosphere levels, H2O + CO2 + O3,
     1-3000 @ 0.001, 8 levels per rank.  Rank 0's and rank 7's blocks (1013 hPa ... and ... 0.1 hPa,
     where the inner Voigt regions carry most) through ShardedLines.for_engine, per gas, pedestal
     off and on; level 0 and level 63 -- which are the first and last of the 8-level atmosphere the
@@ -384,7 +409,8 @@ def test_config3_blocks_of_the_64_level_job(farm, engine):
     plan = distributed.partition(64, weights, 8)
     for ped in (False, True):
         sharded = distributed.ShardedLines.for_engine(engine, handles, (1, 3001, 1000),
-                                                      remove_pedestal=ped, weights=weights)
+                                                      remove_pedestal=ped, weights=weights,
+                                                      farfield=farfield)
         for rank, row, of8 in ((0, 0, 0), (7, 7, 7)):
             mine = distributed.level_shard(64, rank, 8)
             assert plan.levels_of(rank) == list(range(mine.start, mine.stop)) and \
@@ -395,7 +421,8 @@ def test_config3_blocks_of_the_64_level_job(farm, engine):
                 assert tuple(result[f].shape) == (8, 3_000_000)
                 k = result[f][row].cpu().numpy()
                 check_full(farm, ("c3", f, of8, False), ("c3", f, of8, ped), k, 1, 3001, 1000,
-                           ped, f"config3 rank {rank} of 8, {f} level {mine.start + row} ped={ped}")
+                           ped, f"config3 rank {rank} of 8, {f} level {mine.start + row} "
+                                f"ped={ped} farfield={farfield}")
     for handle in handles.values():
         engine.free(handle)
 
@@ -506,3 +533,38 @@ def test_hitran_shaped_table_whole_grid(farm, engine, farfield):
                        f"hitran-shaped farfield={farfield} ped={ped}")
     finally:
         engine.free(molecule)
+
+
+@pytest.mark.parametrize("formula", ("H2O", "CO2", "O3"))
+def test_default_user_path_at_ten_million_points(farm, engine, formula):
+    """engine.compute(..., farfield=True, remove_pedestal=True) -- the two defaults of
+    Spectroscopy.compute_absorption together -- on configs[4]'s grid (n_per_v = 2000: 1000-point
+    cell-aligned tiles, windows of 102 001 points), every one of 10 M points, at ~1 hPa and at
+    0.1 hPa (narrow cores everywhere: the inner-region pass inside the far-field kernel)."""
+    handle = engine.load(table_from_recipe(uniform(formula)))
+    for level in (FULL_LEVEL, LEVELS256[-1]):
+        t, p, x = level_of(STANDARD256, formula, level)
+        k, evals = engine.compute(handle, t, p, x, 1, 5001, 2000, remove_pedestal=True,
+                                  want_evals=True, farfield=True)
+        check_full(farm, ("c4", formula, level, False), ("c4", formula, level, True), k[0],
+                   1, 5001, 2000, True, f"default path {formula} level {level} n_per_v=2000",
+                   evals)
+    engine.free(handle)
+
+
+@pytest.mark.parametrize("cut", OTHER_CUTS)
+def test_other_cut_offs_whole_grid(farm, engine, cut):
+    """cut_off 5 and 40 (the reference's callers always pass 25, gas_optics.py:46-47, but the
+    argument is part of absorption()'s signature): the 400 k-line CO2 table on all 5 M points,
+    pedestal off and on, direct and with the far-field series.  Windows of 11 001 / 81 001
+    points; with 5 cm-1 a tile's far-field range is a few lines wide, with 40 the pedestal's
+    slots reach 81 cells back."""
+    t, p, x = level_of(SURFACE, "CO2", 0)
+    handle = engine.load(table_from_recipe(uniform("CO2")))
+    for farfield in (False, True):
+        for ped in (False, True):
+            k, evals = engine.compute(handle, t, p, x, 1, 5001, 1000, cut_off=cut,
+                                      remove_pedestal=ped, want_evals=True, farfield=farfield)
+            check_full(farm, ("cut", cut, False), ("cut", cut, ped), k[0], 1, 5001, 1000, ped,
+                       f"CO2 cut_off={cut} ped={ped} farfield={farfield}", evals, cut=cut)
+    engine.free(handle)

@@ -92,3 +92,25 @@ def test_two_rank_line(launcher, ordering):
     assert report["ranks"][1]["bytes_sent_per_step"] == 2*n*8          # H2O + CO2 of its level
     assert report["ranks"][0]["bytes_received_per_step"] == 2*n*8
     assert report["bytes_to_rank0_per_step"] == 2*n*8
+
+
+def test_one_rank_line_with_the_process_group_over_rccl():
+    """`bench.py --gpus 1 --backend nccl --force-group`: the N-GPU flow with N = 1 -- RCCL
+    loaded, a communicator on the device, the step's blocks collected through the grouped
+    send/recv, the barrier and the reductions of the record over it -- so that the first lease of
+    a whole node does not die on library load, HSA_ENABLE_IPC_MODE_LEGACY or stream semantics."""
+    environment = dict(os.environ)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        environment.pop(name, None)
+    line = run([sys.executable, "bench.py", "--gpus", "1", "--backend", "nccl", "--force-group",
+                "--steps", "3", "--warmup", "1"], env=environment)
+    check(line, 1, 3, 1)
+    report = line["distributed"]
+    assert report["world_size"] == 1 and report["backend"] == "nccl"
+    assert report["kernels_to_exchange_ordering"].startswith("device")
+    assert report["rccl_mapped"], report
+    n = 5000000
+    rank0 = report["ranks"][0]
+    assert rank0["exchanges"] >= 3
+    assert rank0["bytes_sent_per_step"] == rank0["bytes_received_per_step"] == 2*n*8
+    assert "cpu_baseline" not in line and "farfield_option" not in line

@@ -138,3 +138,27 @@ def test_exchange_is_ordered_behind_the_kernels_without_a_host_wait(oracle):
         got = copy.cpu().numpy()
         assert np.array_equal(got, np.zeros_like(got) if turn % 2 else expect), turn
     engine.close()
+
+
+def test_rccl_at_world_size_one():
+    """RCCL executed once on the GPU a one-GPU box has, in a child process (a process that holds
+    a GPU is never re-executed): init_process_group("nccl", world_size=1), ShardedLines through
+    its collection step with the rank's blocks sent to itself in one grouped send/recv (strided
+    views of the collected array), calls queued back to back without waiting, all_reduce / reduce
+    on an engine-written block ordered by lbl_order_stream_after_engine, Pending.wait's device
+    branch -- all oracle-checked (tests/rccl_one_rank_worker.py)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_worker.py")],
+                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = proc.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        raise
+    assert proc.returncode == 0 and "rccl one rank ok" in out, out + err[-4000:]
+    assert "librccl" in out
