@@ -261,35 +261,71 @@ def closed_form_evals(table, pressure, v0, vn, n_per_v, cut_off=25):
     return int(length.sum())
 
 
+_WORKER_TABLES = {}
+
+
+def _recipe_table(recipe):
+    """A bench table rebuilt inside a worker from what make_tables() was given (deterministic
+    seeds): nothing but a few numbers travels to the worker."""
+    from pylbl_amd import synthetic
+    table = _WORKER_TABLES.get(recipe)
+    if table is None:
+        formula, v_lo, v_hi, scale, banded, index = recipe
+        table = synthetic.line_table(formula, v_lo, v_hi, scale=scale)
+        if banded:
+            table = synthetic.banded_line_table(formula, v_lo, v_hi, num_lines=table.num_lines,
+                                                bands=8, seed=41 + index)
+        _WORKER_TABLES[recipe] = table
+    return table
+
+
+def _warm_worker(recipes):
+    """Pool initializer: the oracle library loaded and the tables built before anything is timed."""
+    from oracle import oracle
+    oracle.port_library()
+    for recipe in recipes:
+        _recipe_table(recipe)
+
+
 def _cpu_chunk(job):
     """Worker of cpu_baseline_parallel: the C restatement on one sub-grid of the sample."""
     from oracle import oracle
     table, t, p, x, v0, vn, n_per_v, remove_pedestal = job
+    if isinstance(table, tuple):
+        table = _recipe_table(table)
+        table = table.subset((table.nu >= v0 - 26.) & (table.nu <= vn + 26.))
     _, extras = oracle.absorption_port(table, t, p, x, v0, vn, n_per_v,
                                        remove_pedestal=remove_pedestal)
     return extras["evals"]
 
 
 def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, workers, timeout=None,
-                          why=None):
+                          why=None, recipes=None):
     """What a user could do with multiprocessing around the reference's Gas: independent
     (molecule, sub-grid) units of the same grid farmed out over `workers` processes (our C
     restatement on arrays; pedestal off, the units would not be independent with it).
-    timeout: seconds the pool may take (start-up included) before the leg is given up."""
+    timeout: seconds the pool may take (start-up included) before the leg is given up.
+    recipes: {formula: what make_tables() built the table from}: the workers rebuild the
+    (deterministic) tables themselves instead of receiving a slice with every unit -- with
+    hundreds of workers the parent's pickling of the slices is otherwise what is timed."""
     import multiprocessing
     vn = vn_full if sample_cm <= 0 else min(vn_full, v0 + int(sample_cm))
     pieces = max(4*workers, 1)
     edges = np.unique(np.linspace(v0, vn, pieces + 1).astype(int))
     jobs = []
+    weights = []
     for t in tables:
         for lo, hi in zip(edges[:-1], edges[1:]):
-            near = t.subset((t.nu >= lo - 26.) & (t.nu <= hi + 26.))
+            inside = (t.nu >= lo - 26.) & (t.nu <= hi + 26.)
+            near = recipes[t.formula] if recipes else t.subset(inside)
             jobs.append((near, atmos.t[0], atmos.p[0], atmos.vmr[t.formula][0], int(lo),
                          int(hi), n_per_v, False))
-    jobs.sort(key=lambda job: -job[0].num_lines*(job[5] - job[4]))
+            weights.append(int(np.count_nonzero(inside))*(int(hi) - int(lo)))
+    jobs = [jobs[i] for i in np.argsort(-np.asarray(weights), kind="stable")]
     context = multiprocessing.get_context("spawn")
     began = time.perf_counter()
-    pool = context.Pool(workers)
+    pool = context.Pool(workers, initializer=_warm_worker,
+                        initargs=(tuple(recipes.values()) if recipes else (),))
     try:
         # start-up and library load, untimed
         left = None if timeout is None else timeout
@@ -722,22 +758,32 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cp
     vmr = {formula: values[mine] for formula, values in atmos.vmr.items()}
     block = DeviceSpectra(engine, t.size, grid.size)
 
-    def step():
+    def step_one_by_one():
         for i, continuum in enumerate(continua):
             continuum.spectra_levels(t, p, vmr, grid, out=block, accumulate=i > 0,
                                      asynchronous=True)
-    for _ in range(2):
-        step()
-    engine.synchronize()
-    engine.set_option("timing", 1)
-    engine.timing(reset=True)
-    start = time.perf_counter()
-    for _ in range(steps):
-        step()
-    engine.synchronize()
-    elapsed = time.perf_counter() - start
-    kernel_ms, launches = engine.timing(reset=True)
-    engine.set_option("timing", 0)
+
+    def step():
+        # every continuum in ONE pass over the grid (lbl_continuum_compute_many): what
+        # Spectroscopy queues for the continua of a gas / of all gases
+        mt_ckd.spectra_levels_many(continua, t, p, vmr, grid, block, asynchronous=True)
+
+    def timed(run):
+        for _ in range(2):
+            run()
+        engine.synchronize()
+        engine.set_option("timing", 1)
+        engine.timing(reset=True)
+        start = time.perf_counter()
+        for _ in range(steps):
+            run()
+        engine.synchronize()
+        seconds = time.perf_counter() - start
+        ms, counts = engine.timing(reset=True)
+        engine.set_option("timing", 0)
+        return seconds, ms, counts
+    separate_s, separate_ms, _ = timed(step_one_by_one)
+    elapsed, kernel_ms, launches = timed(step)
     block.free()
     cpu = None
     if with_cpu:
@@ -755,24 +801,35 @@ def continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, steps, with_cp
                "cores": 1, "kind": "port",
                "sample": f"{'+'.join(owners)} for one level on the same {grid.size} points "
                          f"({seconds:.2f} s)"}
-    adding = len(continua) - 1
-    bytes_per_step = grid.size*t.size*(16*len(continua) + 8*adding)
+    # One pass: the wavenumber in, the extinction out (what the reference's numpy.interp reads and
+    # writes per continuum, utils.py:171-173) -- 16 algorithmic bytes per point and level, once.
+    bytes_per_step = grid.size*t.size*16
     interp_seconds = kernel_ms[5]*1e-3/steps
     achieved = bytes_per_step/interp_seconds/1e9
+    adding = len(continua) - 1
     return {
         "workload": f"MT-CKD continua {'+'.join(owners)} summed into one [levels, points] block "
-                    f"in HBM, {t.size} level(s), {grid.size} points",
+                    f"in HBM in ONE pass over the grid, {t.size} level(s), {grid.size} points",
         "ms_per_step": elapsed/steps*1e3,
         "spectra_per_s": t.size*steps/elapsed,
         "value": len(owners)*grid.size*t.size*steps/elapsed, "unit": "continuum x grid points/s",
         "cpu_baseline": cpu,
         "kernel_ms_per_step": {"band_spectra": kernel_ms[4]/steps, "interpolate": kernel_ms[5]/steps},
+        "one_launch_per_continuum": {
+            "ms_per_step": separate_s/steps*1e3,
+            "kernel_ms_per_step": {"band_spectra": separate_ms[4]/steps,
+                                   "interpolate": separate_ms[5]/steps},
+            "algorithmic_bytes_per_step": grid.size*t.size*(16*len(continua) + 8*adding),
+            "note": "the same sum as round 4 formed it: the first continuum writes the block, "
+                    "every other one is a read-modify-write pass (bit-identical results)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved/HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "lbl::continuum_interp_kernel",
+                     "kernel": "lbl::group_interp_kernel",
                      "avg_launch_ms": kernel_ms[5]/max(launches[5], 1),
                      "note": "16 algorithmic bytes per point and level (wavenumber in, extinction "
-                             "out; +8 when adding into the block); HIP events on the engine's stream"},
+                             "out), once for all continua of the group; the kernel itself forms "
+                             "the wavenumber of an arithmetic grid (numpy.arange) in registers and "
+                             "moves 8; HIP events on the engine's stream"},
     }
 
 
@@ -1124,12 +1181,16 @@ def run():
 
     def count_evals():
         """Closed-form evals of this rank's units (the engine's own count, one blocking pass)."""
+        from pylbl_amd.engine import DeviceSpectra
         total = 0
         for m, levels in plan.by_molecule(rank).items():
             formula = molecules[m]
+            # (spectra into a scratch block in HBM: no 40 MB-class copy to the host for a count)
+            scratch = DeviceSpectra(engine, len(levels), n)
             _, evals = engine.compute(handles[formula], atmos.t[levels], atmos.p[levels],
                                       vmr[formula][levels], *grid_args,
-                                      remove_pedestal=args.pedestal, want_evals=True)
+                                      remove_pedestal=args.pedestal, want_evals=True, out=scratch)
+            scratch.free()
             total += evals
         return total
 
@@ -1351,13 +1412,16 @@ def run():
             # time, and an event-timed launch is stretched by its neighbour.  The fraction is
             # therefore taken from the same launches run alone (blocking calls, one lane), outside
             # the timed region; what the events read inside it is kept beside it.
+            from pylbl_amd.engine import DeviceSpectra
             engine.set_option("timing", 2)
             engine.timing(reset=True)
-            for _ in range(3):
-                for m, levels in plan.by_molecule(rank).items():
+            for m, levels in plan.by_molecule(rank).items():
+                scratch = DeviceSpectra(engine, len(levels), n)
+                for _ in range(3):
                     engine.compute(handles[molecules[m]], atmos.t[levels], atmos.p[levels],
                                    vmr[molecules[m]][levels], *grid_args,
-                                   remove_pedestal=args.pedestal)
+                                   remove_pedestal=args.pedestal, out=scratch)
+                scratch.free()
             alone_ms, alone_launches = engine.timing(reset=True)
             engine.set_option("timing", 0)
             alone = alone_ms[2]/max(alone_launches[2], 1)
@@ -1614,7 +1678,7 @@ def run():
                                   not args.no_cpu_baseline)
             if extra is not None:
                 line["continuum_slot"] = extra
-                traffic, source = profiled_traffic(workload, "continuum_interp_kernel")
+                traffic, source = profiled_traffic(workload, "group_interp_kernel")
                 if traffic is not None:
                     extra["roofline"]["traffic"] = traffic
                     extra["roofline"]["traffic_source"] = f"profiles/{source}"
@@ -1640,7 +1704,9 @@ def run():
                 line["cpu_baseline_all_cores"] = cpu_baseline_parallel(
                     tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, every,
                     timeout=args.cpu_pool_timeout,
-                    why="--cpu-all-cores: every hardware thread this process may run on")
+                    why="--cpu-all-cores: every hardware thread this process may run on",
+                    recipes={f: (f, v_lo, v_hi, args.line_scale, bool(args.banded), i)
+                             for i, f in enumerate(molecules)})
         line["environment"] = {
             "variables": {k: v for k, v in sorted(os.environ.items())
                           if k.startswith("PYLBL_AMD_") or k in ("LBL_DEVICE", "LBL_COMPAT_CACHE",

@@ -285,7 +285,10 @@ int lbl_continuum_load(lbl_engine *engine, int32_t n_bands, const lbl_band *band
 int lbl_continuum_free(lbl_engine *engine, int32_t continuum);
 
 /* Uploads a spectral grid [cm-1] (any ascending array; the reference interpolates onto the
- * caller's own array, utils.py:171-173) and keeps it in HBM. */
+ * caller's own array, utils.py:171-173) and keeps it in HBM.  A grid whose every element equals
+ * first + i*(second - first) in double precision -- what numpy.arange fills -- is recognised
+ * (checked element by element), and the interpolation kernels then form the wavenumber in
+ * registers, the same bits, instead of reading it. */
 int lbl_grid_load(lbl_engine *engine, int64_t n, const double *wavenumber, int32_t *grid);
 int lbl_grid_free(lbl_engine *engine, int32_t grid);
 
@@ -297,6 +300,22 @@ int lbl_continuum_compute(lbl_engine *engine, int32_t continuum, int32_t grid,
                           int32_t n_levels, const double *temperature, const double *pressure,
                           const double *vmr, int32_t flags, double *extinction,
                           int64_t level_stride);
+
+/* Several continua in ONE pass over the grid: what compute_absorption does with the continua of
+ * a gas (spectroscopy.py:193-197 adds each of them into mechanism slot 1; water vapour has two,
+ * :58-61) and, in its "gas" / "total" formats, with the slots of all gases (:225-234).
+ *   continua: n_continua handles, evaluated and added in this order -- every continuum's bands
+ *   summed from zero, then continuum after continuum onto the block: the same values, bit for
+ *   bit, as n_continua calls of lbl_continuum_compute (the first writing, the others with
+ *   LBL_ACCUMULATE), at 8 (+ 8 with LBL_ACCUMULATE) bytes of HBM traffic per point and level
+ *   instead of 16 + 24 (n_continua - 1);
+ *   vmr: [n_continua][n_levels][LBL_VMR_COUNT] (LBL_VMR_SELF differs between the continua);
+ *   extinction: device memory only (LBL_OUT_DEVICE required); LBL_ASYNC, LBL_ACCUMULATE and
+ *   level_stride as for lbl_continuum_compute.  At most 64 bands in all. */
+int lbl_continuum_compute_many(lbl_engine *engine, int32_t n_continua, const int32_t *continua,
+                               int32_t grid, int32_t n_levels, const double *temperature,
+                               const double *pressure, const double *vmr, int32_t flags,
+                               double *extinction, int64_t level_stride);
 
 /* Coarse spectra [cm-1] of every band for one level, concatenated in band order:
  * Continuum.spectra(temperature, pressure [mb], vmr) (utils.py:98-108). */

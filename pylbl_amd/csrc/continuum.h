@@ -268,6 +268,47 @@ __device__ __forceinline__ void store_points(double * __restrict__ row, long lon
     }
 }
 
+// The caller's spectral grid as the interpolation kernels see it.  The reference hands its
+// continua and cross-sections whatever array the user built (spectroscopy.py:195,203), almost
+// always numpy.arange(lo, hi, step), whose elements are first + i*(second - first) in double
+// precision.  lbl_grid_load checks exactly that, element by element; where it holds the kernels
+// form the wavenumber in registers -- the same bits -- instead of reading 8 bytes per point and
+// waiting for them before the table look-ups can start.
+struct GridForm
+{
+    const double * wavenumber;
+    int arithmetic;             // 1: wavenumber[i] == start + (double)i*step for every i (verified)
+    double start, step;
+};
+
+__device__ __forceinline__ double wavenumber_at(const GridForm & form, long long i)
+{
+    if (form.arithmetic)
+    {
+        const double offset = (double)i*form.step;      // (product rounded, then the sum)
+        return form.start + offset;
+    }
+    return form.wavenumber[i];
+}
+
+template <int PT, typename Index>
+__device__ __forceinline__ void load_wavenumbers(const GridForm & form, long long n,
+                                                 const Index & index, double (&x)[PT])
+{
+    if (form.arithmetic)
+    {
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+        {
+            const long long i = index(p);
+            const double offset = (double)i*form.step;
+            x[p] = i < n ? form.start + offset : __builtin_nan("");
+        }
+        return;
+    }
+    load_points<PT>(form.wavenumber, n, index, x, __builtin_nan(""));
+}
+
 // numpy.interp(x, xp, fp, left=0, right=0) for every band, xp[j] = lower + j*resolution
 // (numpy/core/src/multiarray/compiled_base.c, arr_interp: interval by search, then
 // slope*(x - xp[j]) + fp[j], fp[j] itself on a knot, the same fallbacks for a NaN result).
@@ -278,11 +319,80 @@ __device__ __forceinline__ void store_points(double * __restrict__ row, long lon
 // the coarse spectrum from L2), so every thread carries kInterpPoints independent points.
 //
 // grid = (points / (256 PT), levels / LV).  extinction[level][i] (+)= 100 * sum over bands.
+// One band's contribution for PT points x LV levels of a thread: total[p][l] += 100 * interp.
+// `row` = offset of the band's coarse spectrum of the first of the thread's levels; a level's
+// spectra are `level_points` doubles apart.  Returns false when the whole wavefront lies outside
+// the band (nothing was read).
+template <int PT, int LV>
+__device__ __forceinline__ bool add_band(const Band & b, const double * __restrict__ coarse,
+                                         const double * __restrict__ slopes, long long row,
+                                         long long level_points, int count, const double (&x)[PT],
+                                         double (&total)[PT][LV])
+{
+    const int last = b.size - 1;
+    const double x_last = b.lower + (double)last*b.resolution;
+    const double per_step = 1./b.resolution;
+    int j[PT];
+    double dx[PT];
+    bool inside[PT], on_knot[PT];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+        inside[p] = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
+        int at = inside[p] ? (int)((x[p] - b.lower)*per_step) : 0;
+        at = at < 0 ? 0 : (at > last ? last : at);
+        if (inside[p])
+        {
+            // Largest j with xp[j] <= x, whatever the rounding of the product did.
+            while (at < last && b.lower + (double)(at + 1)*b.resolution <= x[p]) ++at;
+            while (at > 0 && b.lower + (double)at*b.resolution > x[p]) --at;
+        }
+        const double xj = b.lower + (double)at*b.resolution;
+        j[p] = at;
+        dx[p] = x[p] - xj;
+        on_knot[p] = (at == last || xj == x[p]);
+        any = any || inside[p];
+    }
+    if (__ballot(any) == 0ull) return false;            // the whole wavefront lies outside
+    double f[PT][LV], slope[PT][LV];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+        {
+            const long long at = row + (long long)(l < count ? l : 0)*level_points + j[p];
+            f[p][l] = coarse[at];
+            slope[p][l] = slopes[at];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+        {
+            double value = on_knot[p] ? f[p][l] : slope[p][l]*dx[p] + f[p][l];
+            if (value != value && inside[p] && !on_knot[p] && l < count)
+            {
+                const long long at = row + (long long)l*level_points + j[p];
+                const double xn = b.lower + (double)(j[p] + 1)*b.resolution;
+                const double fn = coarse[at + 1];
+                value = slope[p][l]*(x[p] - xn) + fn;
+                if (value != value && f[p][l] == fn) value = f[p][l];
+            }
+            if (inside[p]) total[p][l] += value*100.;         // utils.py:171-173
+        }
+    }
+    return true;
+}
+
 template <int kInterpPoints, int kInterpLevels>
 __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
                                                                const double * __restrict__ coarse,
                                                                const double * __restrict__ slopes,
-                                                               const double * __restrict__ wavenumber,
+                                                               GridForm form,
                                                                long long n, int n_levels,
                                                                double * __restrict__ out,
                                                                long long level_stride, int accumulate)
@@ -298,7 +408,7 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
     const int level0 = blockIdx.y*kInterpLevels;
     const int count = min(kInterpLevels, n_levels - level0);
     double x[kInterpPoints];
-    load_points<kInterpPoints>(wavenumber, n, point_index, x, __builtin_nan(""));
+    load_wavenumbers<kInterpPoints>(form, n, point_index, x);
     double total[kInterpPoints][kInterpLevels], before[kInterpPoints][kInterpLevels];
 #pragma unroll
     for (int l = 0; l < kInterpLevels; ++l)
@@ -322,63 +432,9 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
     for (int k = 0; k < set.n_bands; ++k)
     {
         const Band & b = set.band[k];
-        const int last = b.size - 1;
-        const double x_last = b.lower + (double)last*b.resolution;
-        const double per_step = 1./b.resolution;
-        int j[kInterpPoints];
-        double dx[kInterpPoints];
-        bool inside[kInterpPoints], on_knot[kInterpPoints];
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < kInterpPoints; ++p)
-        {
-            inside[p] = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
-            int at = inside[p] ? (int)((x[p] - b.lower)*per_step) : 0;
-            at = at < 0 ? 0 : (at > last ? last : at);
-            if (inside[p])
-            {
-                // Largest j with xp[j] <= x, whatever the rounding of the product did.
-                while (at < last && b.lower + (double)(at + 1)*b.resolution <= x[p]) ++at;
-                while (at > 0 && b.lower + (double)at*b.resolution > x[p]) --at;
-            }
-            const double xj = b.lower + (double)at*b.resolution;
-            j[p] = at;
-            dx[p] = x[p] - xj;
-            on_knot[p] = (at == last || xj == x[p]);
-            any = any || inside[p];
-        }
-        if (__ballot(any) == 0ull) continue;          // the whole wavefront lies outside
-        const long long base = (long long)level0*set.coarse_points + b.spectrum;
-        double f[kInterpPoints][kInterpLevels], slope[kInterpPoints][kInterpLevels];
-#pragma unroll
-        for (int p = 0; p < kInterpPoints; ++p)
-        {
-#pragma unroll
-            for (int l = 0; l < kInterpLevels; ++l)
-            {
-                const long long at = base + (long long)(l < count ? l : 0)*set.coarse_points + j[p];
-                f[p][l] = coarse[at];
-                slope[p][l] = slopes[at];
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < kInterpPoints; ++p)
-        {
-#pragma unroll
-            for (int l = 0; l < kInterpLevels; ++l)
-            {
-                double value = on_knot[p] ? f[p][l] : slope[p][l]*dx[p] + f[p][l];
-                if (value != value && inside[p] && !on_knot[p] && l < count)
-                {
-                    const long long at = base + (long long)l*set.coarse_points + j[p];
-                    const double xn = b.lower + (double)(j[p] + 1)*b.resolution;
-                    const double fn = coarse[at + 1];
-                    value = slope[p][l]*(x[p] - xn) + fn;
-                    if (value != value && f[p][l] == fn) value = f[p][l];
-                }
-                if (inside[p]) total[p][l] += value*100.;         // utils.py:171-173
-            }
-        }
+        add_band<kInterpPoints, kInterpLevels>(
+            b, coarse, slopes, (long long)level0*set.coarse_points + b.spectrum,
+            set.coarse_points, count, x, total);
     }
 #pragma unroll
     for (int l = 0; l < kInterpLevels; ++l)
@@ -392,6 +448,129 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
         }
         store_points<kInterpPoints>(out + (long long)(level0 + l)*level_stride, n, point_index,
                                     row);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several continua in one pass (round 5).  Spectroscopy.compute_absorption adds, per gas, every
+// continuum of the gas into mechanism slot 1 (spectroscopy.py:193-197; H2O has two, :58-61), and
+// the "gas" / "total" formats then add slots and gases (:225-234): as separate launches every
+// continuum after the first is a read-modify-write pass over the block (16 + 24 (owners - 1) bytes
+// per point and level), each behind its own level copy and band kernel.  A group evaluates all of
+// its continua per grid point and writes once: 8 bytes per point and level on an arithmetic grid
+// (+ 8 when it adds into the block).  The sum is formed in the order the separate launches form
+// it -- every continuum's bands from zero, then continuum after continuum onto what was there --
+// so the values are the same bits.
+struct GroupBand
+{
+    Band band;              // band.spectrum: offset inside the GROUP's per-level row of coarse spectra
+    const double * table;   // the owning continuum's coefficient table
+    int owner;              // index of the continuum in the group: its level scalars
+    int first_of_owner;     // 1: the first band of its continuum
+};
+
+constexpr int kMaxGroupBands = 64;
+
+// grid = (coarse points of the widest band / 256, bands of the group, levels);
+// levels[owner*n_levels + level].
+__global__ __launch_bounds__(256) void group_band_spectra_kernel(const GroupBand * __restrict__ bands,
+                                                                 int level_points,
+                                                                 const ContinuumLevel * __restrict__ levels,
+                                                                 int n_levels,
+                                                                 double * __restrict__ coarse,
+                                                                 double * __restrict__ slopes)
+{
+    const GroupBand gb = bands[blockIdx.y];
+    const Band & b = gb.band;
+    const int j = blockIdx.x*256 + threadIdx.x;
+    if (j >= b.size) return;
+    const ContinuumLevel s = levels[(long long)gb.owner*n_levels + blockIdx.z];
+    const long long at = (long long)blockIdx.z*level_points + b.spectrum + j;
+    const double here = band_value(b, gb.table, s, j);
+    coarse[at] = here;
+    double slope = 0.;
+    if (j + 1 < b.size)
+    {
+        const double xj = b.lower + (double)j*b.resolution;
+        const double xn = b.lower + (double)(j + 1)*b.resolution;
+        slope = (band_value(b, gb.table, s, j + 1) - here)/(xn - xj);
+    }
+    slopes[at] = slope;
+}
+
+// grid = (points / (256 PT), levels / LV).  out[level][i] (+)= sum over the group's continua.
+template <int PT, int LV>
+__global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __restrict__ bands,
+                                                           int n_bands, int level_points,
+                                                           const double * __restrict__ coarse,
+                                                           const double * __restrict__ slopes,
+                                                           GridForm form, long long n, int n_levels,
+                                                           double * __restrict__ out,
+                                                           long long level_stride, int accumulate)
+{
+    static_assert(PT == 1 || PT % 2 == 0, "points come in pairs");
+    const long long block_first = (long long)blockIdx.x*(256*PT);
+    auto point_index = [&](int p) -> long long {
+        return PT == 1 ? block_first + threadIdx.x
+                       : block_first + (p >> 1)*512 + 2*threadIdx.x + (p & 1);
+    };
+    const int level0 = blockIdx.y*LV;
+    const int count = min(LV, n_levels - level0);
+    double x[PT];
+    load_wavenumbers<PT>(form, n, point_index, x);
+    double sum[PT][LV], total[PT][LV];
+#pragma unroll
+    for (int l = 0; l < LV; ++l)
+    {
+        double row[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) row[p] = 0.;
+        if (accumulate && l < count)
+        {
+            load_points<PT>(out + (long long)(level0 + l)*level_stride, n, point_index, row, 0.);
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+        {
+            total[p][l] = 0.;
+            sum[p][l] = row[p];
+        }
+    }
+    // (`started`: something has been added to -- or was there before -- the running sum: the
+    // first continuum of a group that writes REPLACES, like the first of the separate launches.)
+    bool started = accumulate != 0;
+    auto fold = [&]() {
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+        {
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+            {
+                // (the order of the separate launches: what this continuum sums to, onto what
+                // was there)
+                sum[p][l] = started ? total[p][l] + sum[p][l] : total[p][l];
+                total[p][l] = 0.;
+            }
+        }
+        started = true;
+    };
+    for (int k = 0; k < n_bands; ++k)
+    {
+        const GroupBand * gb = bands + k;       // wave-uniform: scalar loads
+        if (k > 0 && gb->first_of_owner) fold();
+        add_band<PT, LV>(gb->band, coarse, slopes,
+                         (long long)level0*level_points + gb->band.spectrum, level_points, count,
+                         x, total);
+    }
+    fold();
+#pragma unroll
+    for (int l = 0; l < LV; ++l)
+    {
+        if (l >= count) continue;
+        double row[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) row[p] = sum[p][l];
+        store_points<PT>(out + (long long)(level0 + l)*level_stride, n, point_index, row);
     }
 }
 

@@ -98,6 +98,7 @@ int lbl_engine_destroy(lbl_engine * engine)
     }
     for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
     engine->molecules.clear();
+    engine->groups.clear();
     engine->continua.clear();
     engine->xsecs.clear();
     engine->grids.clear();

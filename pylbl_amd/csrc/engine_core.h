@@ -357,7 +357,27 @@ struct SpectralGrid
 {
     long long n = 0;
     bool ascending = true;
+    // wavenumber[i] == start + (double)i*step for every i, checked element by element at load
+    // (what numpy.arange produces): the interpolation kernels then form x in registers.
+    bool arithmetic = false;
+    double start = 0., step = 0.;
     DeviceBuffer<double> wavenumber;
+
+    GridForm form() const
+    {
+        return GridForm{wavenumber.data, arithmetic ? 1 : 0, start, step};
+    }
+};
+
+// Several continua evaluated in one pass (continuum.h, group kernels): the bands of all of them
+// in one list on the device, one workspace of coarse spectra, one block of level scalars
+// [continuum][level].  Kept per list of handles; dropped when one of them is freed.
+struct ContinuumGroup : LevelFeed<ContinuumLevel>
+{
+    std::vector<int32_t> members;
+    DeviceBuffer<GroupBand> bands;
+    int n_bands = 0, level_points = 0, widest = 0;
+    DeviceBuffer<double> coarse, slopes;    // [levels][level_points]
 };
 
 }  // namespace
@@ -391,6 +411,7 @@ struct lbl_engine
     std::vector<std::unique_ptr<ContinuumSet>> continua;
     std::vector<std::unique_ptr<SpectralGrid>> grids;
     std::vector<std::unique_ptr<XsecData>> xsecs;
+    std::vector<std::unique_ptr<ContinuumGroup>> groups;
     Lane lanes[kAllLanes];
     unsigned next_lane = 0;
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
                                                           const double * __restrict__ values,
                                                           const double * __restrict__ slopes,
                                                           const XsecLevel * __restrict__ levels,
-                                                          const double * __restrict__ wavenumber,
+                                                          GridForm form,
                                                           long long n, int n_levels, int ascending,
                                                           double * __restrict__ out,
                                                           long long level_stride, int accumulate)
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
         if (ascending)
         {
             const long long block_last = min(block_first + 256*PT, n) - 1;
-            const double x_lo = wavenumber[block_first]*kSpeedOfLight*100;
-            const double x_hi = wavenumber[block_last]*kSpeedOfLight*100;
+            const double x_lo = wavenumber_at(form, block_first)*kSpeedOfLight*100;
+            const double x_hi = wavenumber_at(form, block_last)*kSpeedOfLight*100;
             lo = lower_bound(fgrid + b.offset, 0, b.size, x_lo);
             hi = lower_bound(fgrid + b.offset, lo, b.size, x_hi);
         }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
         window[threadIdx.x][1] = hi;
     }
     double x[PT], total[PT][LV], before[PT][LV];
-    load_points<PT>(wavenumber, n, point_index, x, __builtin_nan(""));
+    load_wavenumbers<PT>(form, n, point_index, x);
 #pragma unroll
     for (int p = 0; p < PT; ++p)
     {

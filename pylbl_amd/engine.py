@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "lbl_line_scalars", "lbl_absorption", "absorption", "lbl_compat_state", "lbl_fill_zero",
     "lbl_version",
     "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
-    "lbl_continuum_compute", "lbl_continuum_bands",
+    "lbl_continuum_compute", "lbl_continuum_compute_many", "lbl_continuum_bands",
     "lbl_xsec_load", "lbl_xsec_free", "lbl_xsec_compute", "lbl_xsec_bands",
 )
 
@@ -140,6 +140,9 @@ def library():
     lib.lbl_grid_free.argtypes = [c_void_p, c_int32]
     lib.lbl_continuum_compute.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_void_p, c_int64]
+    lib.lbl_continuum_compute_many.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                               c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                               c_int64]
     lib.lbl_continuum_bands.argtypes = [c_void_p, c_int32, c_double, c_double, c_void_p,
                                         c_void_p]
     lib.lbl_xsec_load.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, i32p]
@@ -540,6 +543,26 @@ class Engine(object):
         self._check(self.lib.lbl_continuum_compute(
             self.handle, int(continuum), int(grid), t.size, t.ctypes.data, p.ctypes.data,
             x.ctypes.data, flags, pointer, stride))
+        return out
+
+    def continuum_compute_many(self, continua, grid, n, temperature, pressure, vmr, out,
+                               accumulate=False, asynchronous=False):
+        """Several continua in one pass over the grid (lbl_continuum_compute_many): summed, in
+        the order given, into the DeviceSpectra `out` [levels, >= n] -- the same bits as one
+        continuum_compute per handle, at a third of the HBM traffic for three of them.
+        vmr: [len(continua), levels, VMR_COUNT]."""
+        t, p = _f64(np.atleast_1d(temperature)), _f64(np.atleast_1d(pressure))
+        handles = np.ascontiguousarray(continua, dtype=np.int32)
+        x = _f64(vmr).reshape(handles.size, -1, VMR_COUNT)
+        if not (t.ndim == 1 and t.shape == p.shape and x.shape[1] == t.size):
+            raise ValueError("temperature, pressure [levels] and vmr [continua, levels, 5] disagree.")
+        if not hasattr(out, "pointer"):
+            raise ValueError("continuum_compute_many writes a block in HBM (DeviceSpectra).")
+        flags = (ACCUMULATE if accumulate else 0) | (ASYNC if asynchronous else 0)
+        out, pointer, flags, stride = self._output(out, t.size, n, flags)
+        self._check(self.lib.lbl_continuum_compute_many(
+            self.handle, handles.size, handles.ctypes.data, int(grid), t.size, t.ctypes.data,
+            p.ctypes.data, x.ctypes.data, flags, pointer, stride))
         return out
 
     def _output(self, out, levels, n, flags):

@@ -246,6 +246,33 @@ class OzoneContinuum(BandedContinuum):
               _tabulated(O3_HARTLEY, "o3_hh0", "o3_hh1", "o3_hh2"), _tabulated(O3_UV, "o3_huv"))
 
 
+def spectra_levels_many(continua, temperature, pressure, vmr, grid, out, accumulate=False,
+                        asynchronous=False):
+    """Every continuum of `continua` (BandedContinuum objects of one engine) for all levels in
+    ONE pass over the grid, summed in that order into the DeviceSpectra `out`
+    (lbl_continuum_compute_many): what compute_absorption's loops over a gas's continua
+    (pyLBL/spectroscopy.py:193-197) and, in its "gas" / "total" formats, over the gases
+    (:225-234) amount to -- the same bits as one spectra_levels(..., accumulate=True) per
+    continuum."""
+    continua = list(continua)
+    if not continua:
+        return out
+    engine = continua[0].engine
+    if len(continua) == 1 or any(c.engine is not engine for c in continua) or \
+            sum(len(c.bands) for c in continua) > 64:
+        for i, continuum in enumerate(continua):
+            continuum.spectra_levels(temperature, pressure, vmr, grid, out=out,
+                                     accumulate=accumulate or i > 0, asynchronous=asynchronous)
+        return out
+    t = np.atleast_1d(np.asarray(temperature, dtype=np.float64))
+    grid = grid if isinstance(grid, np.ndarray) and grid.dtype == np.float64 and \
+        grid.flags["C_CONTIGUOUS"] else np.ascontiguousarray(grid, dtype=np.float64)
+    packed = np.stack([c.pack_vmr(vmr, t.size) for c in continua])
+    return engine.continuum_compute_many(
+        [c.handle for c in continua], resident_grid(engine, grid), grid.size, t, pressure,
+        packed, out, accumulate=accumulate, asynchronous=asynchronous)
+
+
 # The dictionary pyLBL.plugins builds for the group "mt_ckd" (plugins.py:24-34): the part of
 # the entry-point name in front of "Continuum" -> class.
 CONTINUA = {"CO2": CarbonDioxideContinuum, "H2OForeign": WaterVaporForeignContinuum,

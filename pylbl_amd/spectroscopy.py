@@ -346,11 +346,25 @@ class Spectroscopy(object):
                 asynchronous=True, farfield=self.farfield, deliver=deliver,
                 pieces=pieces, defer_finish=defer)
 
-        def slots_into(name, continua_here, cross, continuum_sum, cross_sum):
-            for continuum in continua_here:
+        def continua_into(continua_list, continuum_sum):
+            # All of them in one pass over the grid where they are this package's (one launch that
+            # writes the block once instead of a read-modify-write pass per continuum; the same
+            # bits: csrc/continuum.h, group kernels); anything else one by one.
+            if not continua_list:
+                return
+            from .mt_ckd import BandedContinuum, spectra_levels_many
+            if all(isinstance(c, BandedContinuum) for c in continua_list):
+                spectra_levels_many(continua_list, temperature, pressure, mole_fractions,
+                                    self.grid, continuum_sum.buffer,
+                                    accumulate=continuum_sum.take(), asynchronous=True)
+                return
+            for continuum in continua_list:
                 continuum.spectra_levels(temperature, pressure, mole_fractions, self.grid,
                                          out=continuum_sum.buffer,
                                          accumulate=continuum_sum.take(), asynchronous=True)
+
+        def slots_into(name, continua_here, cross, continuum_sum, cross_sum):
+            continua_into(continua_here, continuum_sum)
             if cross is not None:
                 cross.absorption_coefficients(self.grid, temperature, pressure,
                                               volume_mixing_ratio=mole_fractions[name],
@@ -402,8 +416,12 @@ class Spectroscopy(object):
                         # everything).  (Lines first and the slot kernels behind them was tried: the
                         # slot kernels then wait for the first gas's pedestal to be applied and the
                         # heaviest gas is queued later, 1.58 -> 1.70 ms.)
+                        # (every continuum of every gas in ONE pass -- the block is written once --
+                        # then the cross-sections)
+                        continua_into([c for _, _, continua_here, _ in present
+                                       for c in continua_here], total)
                         for name, gas, continua_here, cross in present:
-                            slots_into(name, continua_here, cross, total, total)
+                            slots_into(name, [], cross, total, total)
                         if not total.written:
                             engine.fill_zero(total.buffer, asynchronous=True)
                             total.take()

@@ -239,3 +239,67 @@ def test_compute_absorption_is_reproducible_call_to_call(tmp_path):
                     assert np.array_equal(value, first[(output_format, key)]), (round_, key)
             del out
             gc.collect()
+
+
+@pytest.mark.parametrize("grid_name", ["reference test grid", "scattered", "near infrared",
+                                        "on the knots"])
+@pytest.mark.parametrize("owners", [("H2OForeign", "H2OSelf"), ("H2OForeign", "H2OSelf", "CO2"),
+                                    OWNERS, ("O2",)])
+def test_several_continua_in_one_pass_give_the_same_bits(continua, continuum_oracle, owners,
+                                                         grid_name):
+    """lbl_continuum_compute_many (what Spectroscopy uses for the continua of a gas, and of all
+    gases in its "total" format, spectroscopy.py:193-197,225-234): bit for bit what one
+    lbl_continuum_compute per continuum leaves in the block -- written by the first, added to by
+    the others -- for 1, 5 and 24 levels, writing and adding onto a block that holds something,
+    on arithmetic grids (numpy.arange: the wavenumber is formed in registers) and on a scattered
+    one (read from HBM); and each within the bar of the oracle's sum."""
+    grid = GRIDS[grid_name]()
+    engine = default_engine(0)
+    for levels in (1, 5, 24):
+        atmos = synthetic.standard_atmosphere(max(levels, 2))
+        t, p = atmos.t[:levels], atmos.p[:levels]
+        vmr = {name: values[:levels] for name, values in atmos.vmr.items()}
+        members = [continua[owner] for owner in owners]
+        padded = grid.size + 9
+        for start in (None, 0.75):
+            one_by_one = DeviceSpectra(engine, levels, padded)
+            together = DeviceSpectra(engine, levels, padded)
+            if start is not None:
+                # something in the block already: a first continuum of another gas, say
+                for block in (one_by_one, together):
+                    continua["O3"].spectra_levels(t, p, vmr, grid, out=block)
+            for i, continuum in enumerate(members):
+                continuum.spectra_levels(t, p, vmr, grid, out=one_by_one,
+                                         accumulate=(start is not None) or i > 0,
+                                         asynchronous=True)
+            mt_ckd.spectra_levels_many(members, t, p, vmr, grid, together,
+                                       accumulate=start is not None, asynchronous=True)
+            engine.synchronize()
+            a = one_by_one.to_host()[:, :grid.size]
+            b = together.to_host()[:, :grid.size]
+            assert np.array_equal(a, b, equal_nan=True), (owners, grid_name, levels, start)
+            if start is None:
+                dictionaries = level_dictionaries(synthetic.Atmos(p=p, t=t, vmr=vmr))
+                expect = sum(np.stack([continuum_oracle.continuum(owner).spectra(
+                    t[i], p[i], dictionaries[i], grid) for i in range(levels)])
+                    for owner in owners)
+                scale = np.max(np.abs(expect))
+                assert np.all(np.abs(b - expect) <= RTOL*np.abs(expect) + 1e-12*scale)
+            one_by_one.free()
+            together.free()
+
+
+def test_arithmetic_grids_are_recognised_exactly(continua, continuum_oracle):
+    """A grid is taken as first + i*step only where every element says so: numpy.arange grids
+    are, numpy.linspace's and an arange grid with ONE element moved by an ulp are not -- and all
+    three give what the oracle gives for the array as it is (the moved point included)."""
+    temperature, pressure, vmr = last_level()
+    exact = np.arange(600., 2600., 0.01)
+    moved = exact.copy()
+    moved[123_457] = np.nextafter(moved[123_457], np.inf)
+    spaced = np.linspace(600., 2600., 200_001)
+    for name, grid in (("arange", exact), ("one ulp off", moved), ("linspace", spaced)):
+        for owner in ("H2OSelf", "CO2"):
+            got = continua[owner].spectra(temperature, pressure, vmr, grid)
+            expect = continuum_oracle.continuum(owner).spectra(temperature, pressure, vmr, grid)
+            assert_close(got, expect, f"{owner} on {name}")
