@@ -50,6 +50,8 @@ struct Band
     int size;               // coarse points
     double lower;           // coarse wavenumber j = lower + j*resolution (utils.py:142-143)
     double resolution;
+    double per_step;        // 1/resolution, formed once on the host (correctly rounded there as
+                            // here: the same bits as the division every thread used to do)
     long long column[4];    // offsets of the coefficient columns in the table, -1 = unused
     long long spectrum;     // offset of this band's coarse spectrum in a level's workspace
 };
@@ -319,6 +321,35 @@ __device__ __forceinline__ void load_wavenumbers(const GridForm & form, long lon
 // the coarse spectrum from L2), so every thread carries kInterpPoints independent points.
 //
 // grid = (points / (256 PT), levels / LV).  extinction[level][i] (+)= 100 * sum over bands.
+// numpy.interp's interval for x in a band with knots xp[j] = lower + j*resolution: the largest j
+// with xp[j] <= x (0 outside the band), and xp[j] itself.  One multiplication lands on it or next
+// to it; the knots beside the guess decide (formed exactly as xp is, so the answer is numpy's
+// search result whatever the product's rounding did).  Every knot is formed once: the two loops
+// used to re-form theirs at every test, a quarter of the kernel's instructions.
+__device__ __forceinline__ int interval_of(const Band & b, int last, double x, bool inside,
+                                           double & xj)
+{
+    int at = inside ? (int)((x - b.lower)*b.per_step) : 0;
+    at = at < 0 ? 0 : (at > last ? last : at);
+    xj = b.lower + (double)at*b.resolution;
+    if (inside)
+    {
+        while (at > 0 && xj > x)
+        {
+            --at;
+            xj = b.lower + (double)at*b.resolution;
+        }
+        double xn = b.lower + (double)(at + 1)*b.resolution;
+        while (at < last && xn <= x)
+        {
+            ++at;
+            xj = xn;
+            xn = b.lower + (double)(at + 1)*b.resolution;
+        }
+    }
+    return at;
+}
+
 // One band's contribution for PT points x LV levels of a thread: total[p][l] += 100 * interp.
 // `row` = offset of the band's coarse spectrum of the first of the thread's levels; a level's
 // spectra are `level_points` doubles apart.  Returns false when the whole wavefront lies outside
@@ -331,7 +362,6 @@ __device__ __forceinline__ bool add_band(const Band & b, const double * __restri
 {
     const int last = b.size - 1;
     const double x_last = b.lower + (double)last*b.resolution;
-    const double per_step = 1./b.resolution;
     int j[PT];
     double dx[PT];
     bool inside[PT], on_knot[PT];
@@ -340,18 +370,10 @@ __device__ __forceinline__ bool add_band(const Band & b, const double * __restri
     for (int p = 0; p < PT; ++p)
     {
         inside[p] = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
-        int at = inside[p] ? (int)((x[p] - b.lower)*per_step) : 0;
-        at = at < 0 ? 0 : (at > last ? last : at);
-        if (inside[p])
-        {
-            // Largest j with xp[j] <= x, whatever the rounding of the product did.
-            while (at < last && b.lower + (double)(at + 1)*b.resolution <= x[p]) ++at;
-            while (at > 0 && b.lower + (double)at*b.resolution > x[p]) --at;
-        }
-        const double xj = b.lower + (double)at*b.resolution;
-        j[p] = at;
+        double xj;
+        j[p] = interval_of(b, last, x[p], inside[p], xj);
         dx[p] = x[p] - xj;
-        on_knot[p] = (at == last || xj == x[p]);
+        on_knot[p] = (j[p] == last || xj == x[p]);
         any = any || inside[p];
     }
     if (__ballot(any) == 0ull) return false;            // the whole wavefront lies outside
@@ -498,8 +520,42 @@ __global__ __launch_bounds__(256) void group_band_spectra_kernel(const GroupBand
     slopes[at] = slope;
 }
 
+// Where a thread's points lie in one band: the interval index, the distance to its lower knot and
+// two bit masks over the points (bit p: inside the band / on a knot).
+template <int PT>
+struct BandPlace
+{
+    int j[PT];
+    double dx[PT];
+    unsigned inside, on_knot;
+};
+
+template <int PT>
+__device__ __forceinline__ void locate_in_band(const Band & b, const double (&x)[PT],
+                                               BandPlace<PT> & place)
+{
+    const int last = b.size - 1;
+    const double x_last = b.lower + (double)last*b.resolution;
+    place.inside = place.on_knot = 0u;
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+    {
+        const bool inside = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
+        double xj;
+        const int at = interval_of(b, last, x[p], inside, xj);
+        place.j[p] = at;
+        place.dx[p] = x[p] - xj;
+        if (inside) place.inside |= 1u << p;
+        if (at == last || xj == x[p]) place.on_knot |= 1u << p;
+    }
+}
+
 // grid = (points / (256 PT), levels / LV).  out[level][i] (+)= sum over the group's continua.
-template <int PT, int LV>
+// The bands are taken NB at a time: the intervals of NB bands are found first, then the table
+// values of all of them are requested together and only then used -- one band after the other
+// (add_band) put the two dependent L2 round trips of every band end to end: 59 us for three
+// continua at 5 M points, where one continuum alone takes 26.
+template <int PT, int LV, int NB>
 __global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __restrict__ bands,
                                                            int n_bands, int level_points,
                                                            const double * __restrict__ coarse,
@@ -554,13 +610,71 @@ __global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __r
         }
         started = true;
     };
-    for (int k = 0; k < n_bands; ++k)
+    for (int k0 = 0; k0 < n_bands; k0 += NB)
     {
-        const GroupBand * gb = bands + k;       // wave-uniform: scalar loads
-        if (k > 0 && gb->first_of_owner) fold();
-        add_band<PT, LV>(gb->band, coarse, slopes,
-                         (long long)level0*level_points + gb->band.spectrum, level_points, count,
-                         x, total);
+        BandPlace<PT> place[NB];
+        bool wanted[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+            wanted[q] = false;
+            place[q].inside = place[q].on_knot = 0u;
+            if (k0 + q < n_bands)
+            {
+                locate_in_band<PT>(bands[k0 + q].band, x, place[q]);
+                wanted[q] = __ballot(place[q].inside != 0u) != 0ull;   // wave-uniform
+            }
+        }
+        double f[NB][PT][LV], slope[NB][PT][LV];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+            if (!wanted[q]) continue;
+            const long long row = (long long)level0*level_points + bands[k0 + q].band.spectrum;
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+            {
+#pragma unroll
+                for (int l = 0; l < LV; ++l)
+                {
+                    const long long at = row + (long long)(l < count ? l : 0)*level_points +
+                                         place[q].j[p];
+                    f[q][p][l] = coarse[at];
+                    slope[q][p][l] = slopes[at];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+        {
+            if (k0 + q >= n_bands) continue;
+            const GroupBand * gb = bands + (k0 + q);        // wave-uniform: scalar loads
+            if (k0 + q > 0 && gb->first_of_owner) fold();
+            if (!wanted[q]) continue;
+            const Band & b = gb->band;
+            const long long row = (long long)level0*level_points + b.spectrum;
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+            {
+                const bool inside = (place[q].inside >> p) & 1u;
+                const bool on_knot = (place[q].on_knot >> p) & 1u;
+#pragma unroll
+                for (int l = 0; l < LV; ++l)
+                {
+                    double value = on_knot ? f[q][p][l]
+                                           : slope[q][p][l]*place[q].dx[p] + f[q][p][l];
+                    if (value != value && inside && !on_knot && l < count)
+                    {
+                        const long long at = row + (long long)l*level_points + place[q].j[p];
+                        const double xn = b.lower + (double)(place[q].j[p] + 1)*b.resolution;
+                        const double fn = coarse[at + 1];
+                        value = slope[q][p][l]*(x[p] - xn) + fn;
+                        if (value != value && f[q][p][l] == fn) value = f[q][p][l];
+                    }
+                    if (inside) total[p][l] += value*100.;         // utils.py:171-173
+                }
+            }
+        }
     }
     fold();
 #pragma unroll

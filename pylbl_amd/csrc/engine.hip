@@ -371,7 +371,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->timing = (int)value;
     }
-    else if (key == "interp_shape" && value >= 0 && value < 100)
+    else if (key == "interp_shape" && value >= 0 && value < 1000)
     {
         engine->interp_shape = (int)value;
     }
