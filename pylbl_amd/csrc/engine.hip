@@ -391,6 +391,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->skip_delivery_lanes = (int)value;
     }
+    else if (key == "chain_first" && (value == 0 || value == 1))
+    {
+        engine->chain_first = (int)value;
+    }
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
