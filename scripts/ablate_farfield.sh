@@ -1,6 +1,6 @@
 #!/bin/bash
 # Which part of the far-field step is what: the diagnostic switches of accumulate_tile on --farfield.
-for ablate in 0 1 2 4 16 32 64 0; do
+for ablate in 0 1 2 3 4 8 16 32 0; do
   python bench.py --steps 10 --warmup 3 --no-extras --farfield --ablate $ablate 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

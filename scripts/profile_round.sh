@@ -19,3 +19,8 @@ scripts/profile_bench.sh ${TAG}_standard8 --levels-per-gpu 8 --profile standard 
 echo "standard8 done"
 scripts/profile_bench.sh ${TAG}_farfield --farfield --pedestal >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
 echo "farfield done"
+# round 5: the far-field legs' own counters (what farfield_option.*.roofline reads)
+scripts/profile_bench.sh ${TAG}_farfield_plain --farfield >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
+scripts/profile_counters.sh ${TAG}_farfield --farfield --pedestal >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
+scripts/profile_counters.sh ${TAG}_farfield_plain --farfield >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
+echo "farfield counters done"
