@@ -153,6 +153,26 @@ def atmosphere_for(levels_total, profile):
     return synthetic.Atmos(p=p, t=t, vmr=vmr)
 
 
+def cpu_quota():
+    """CPUs' worth of time the process may use according to its cgroup (cpu.max, v2; cfs quota,
+    v1), or None when unlimited / not readable: a pool may show every hardware thread of the host
+    in the affinity mask and still be allotted a fraction of them."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as handle:
+            quota, period = handle.read().split()[:2]
+        return None if quota == "max" else float(quota)/float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as handle:
+            quota = float(handle.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as handle:
+            period = float(handle.read())
+        return None if quota <= 0 else quota/period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -347,11 +367,13 @@ def cpu_baseline_parallel(tables, atmos, v0, vn_full, n_per_v, sample_cm, worker
     return {"value": evals/seconds, "unit": "evals/s", "cores": workers, "kind": "port",
             "host_cores": os.cpu_count(),
             "usable_hardware_threads": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_quota_cores": cpu_quota(),
             "pool_start_s": ready - began,
             "sample": f"the grid {v0}-{vn} cm-1 cut into {len(jobs)} (molecule, sub-grid) "
                       f"units over {workers} processes ({why or '--cpu-workers'}; the host has "
                       f"{os.cpu_count()} hardware threads, "
-                      f"{len(os.sched_getaffinity(0))} usable by this process), {evals:.4g} evals "
+                      f"{len(os.sched_getaffinity(0))} in this process's affinity mask, cgroup CPU "
+                      f"quota {cpu_quota() or 'none'} cores), {evals:.4g} evals "
                       f"in {seconds:.2f} s (+ {ready - began:.1f} s to start the pool, untimed)"}
 
 

@@ -21,7 +21,7 @@
 namespace lbl {
 
 // 1/t for t well inside the normal range: v_rcp_f64 (about 25 good bits on gfx950) plus
-// one Newton step; measured max relative error 1.4e-15 (scripts/ubench_fp64.hip).
+// one Newton step; measured max relative error 1.4e-15 (scripts/ubench/ubench_fp64.hip).
 __device__ __forceinline__ double rcp_newton(double t)
 {
     double r = __builtin_amdgcn_rcp(t);

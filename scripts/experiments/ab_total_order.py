@@ -1,17 +1,17 @@
 """Spectroscopy.compute_absorption("total"): the heaviest gas queued first and finished last
 (LBL_DEFER_FINISH, round 3) against queued last and delivering piece by piece (round 4), in one
-process, alternating.  Usage on the GPU box: python scripts/ab_total_order.py [pieces ...]"""
+process, alternating.  Usage on the GPU box: python scripts/experiments/ab_total_order.py [pieces ...]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pylbl_amd import MemoryDatabase, Spectroscopy, synthetic  # noqa: E402
 
-os.environ.setdefault("PYLBL_MT_CKD", os.path.join(os.path.dirname(os.path.dirname(
-    os.path.abspath(__file__))), "tests", "golden", "mt_ckd_bands.npz"))
+os.environ.setdefault("PYLBL_MT_CKD", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))), "tests", "golden", "mt_ckd_bands.npz"))
 pieces = [int(x) for x in sys.argv[1:]] or [2, 4, 6, 8]
 tables = [synthetic.line_table(f, 1., 5000.) for f in ("H2O", "CO2")]
 surface = synthetic.surface_level()

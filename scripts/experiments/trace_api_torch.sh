@@ -1,10 +1,10 @@
 #!/bin/bash
-# HIP API statistics of scripts/bisect_api.py with and without a torch kernel launched first.
+# HIP API statistics of scripts/experiments/bisect_api.py with and without a torch kernel launched first.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for m in plain torch; do
   rm -rf $R/gpurun_out/api_$m
-  rocprofv3 --hip-trace --stats --output-format csv -d $R/gpurun_out/api_$m -- python3 $R/scripts/bisect_api.py $m > $R/gpurun_out/api_$m.log 2>&1
+  rocprofv3 --hip-trace --stats --output-format csv -d $R/gpurun_out/api_$m -- python3 $R/scripts/experiments/bisect_api.py $m > $R/gpurun_out/api_$m.log 2>&1
   echo "== $m: $(grep total $R/gpurun_out/api_$m.log | tr '\n' ' ')"
   f=$(find $R/gpurun_out/api_$m -name "*hip_api_stats.csv" | head -1)
   python3 - "$f" <<'PY'

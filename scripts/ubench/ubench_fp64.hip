@@ -3,7 +3,7 @@
 // bodies (one reciprocal per evaluation, shared reciprocal for 2 / 4 lines,
 // fp32-seeded reciprocal, IEEE division).  Not part of the product.
 //
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off scripts/ubench_fp64.hip -o /tmp/ubench
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off scripts/ubench/ubench_fp64.hip -o /tmp/ubench
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // four), a loop of one MFMA plus K independent v_fma_f64 fillers; cycles per iteration from
 // s_memtime.  Also prints the C/D register layout of the instruction.  Not part of the product.
 //
-//   hipcc -O3 --offload-arch=gfx950 scripts/ubench_mfma_f64.hip -o /tmp/ubench_mfma
+//   hipcc -O3 --offload-arch=gfx950 scripts/ubench/ubench_mfma_f64.hip -o /tmp/ubench_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -5,7 +5,7 @@
 // 33 FMA-class + 1 v_rcp_f64 per 8 lines and point.  Both loops read wave-uniform records
 // through the scalar cache like the product kernel.  Not part of the product.
 //
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off scripts/ubench_poly.hip -o /tmp/ubench_poly
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off scripts/ubench/ubench_poly.hip -o /tmp/ubench_poly
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
