@@ -433,7 +433,7 @@ struct lbl_engine
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
     int skip_delivery_lanes = 1;    // delivering calls avoid lanes that share the copy stream's queue
-    int chain_first = 1;            // far-field calls queue the pedestal chain before the accumulate launches
+    int chain_first = 0;            // 1: far-field calls queue the pedestal chain before the accumulate launches (+-0)
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };

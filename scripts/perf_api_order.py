@@ -24,7 +24,7 @@ options = [x for x in os.environ.get("AB_OPTIONS", "").split(";")]      # "name=
 for round_ in range(3):
     for order in [o for o in os.environ.get("ORDERS", "heavy_last,deferred").split(",")]:
       for option in options:
-        for pair in ("chain_first=1",) + tuple(filter(None, option.split())):
+        for pair in tuple(filter(None, option.split())):
             default_engine(0).set_option(pair.split("=")[0], int(pair.split("=")[1]))
         for count in pieces:
             spec.total_order = order
