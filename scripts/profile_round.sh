@@ -9,7 +9,7 @@ set -o pipefail
 TAG=${1:-r03a}
 EXTRAS=continuum scripts/profile_bench.sh ${TAG} > gpurun_out/profile_${TAG}.log 2>&1 || exit 1
 echo "default done"
-scripts/profile_counters.sh ${TAG} >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
+EXTRAS=continuum scripts/profile_counters.sh ${TAG} >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
 echo "counters done"
 scripts/profile_bench.sh ${TAG}_pedestal --pedestal >> gpurun_out/profile_${TAG}.log 2>&1 || exit 1
 echo "pedestal done"

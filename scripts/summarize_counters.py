@@ -20,7 +20,7 @@ launches_per_step = line["roofline"]["launches_timed"]/line["steps"]
 summary = {
     "tag": tag,
     "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
-               "--no-extras (one pass per group, scripts/profile_counters.sh)",
+               "--no-cpu-baseline --extras $EXTRAS (one pass per group, scripts/profile_counters.sh)",
     "workload": line["config"]["workload"],
     "evals_per_accumulate_launch": line["evals_per_step"]/launches_per_step,
     "kernels": {},

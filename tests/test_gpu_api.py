@@ -752,6 +752,62 @@ def test_deferred_finish_queued_first_adds_last(farfield):
     e.close()
 
 
+def test_frees_of_other_memory_leave_a_deferred_call_alone():
+    """lbl_host_free / lbl_device_free finish a call kept back (LBL_DEFER_FINISH) only
+    when the memory released is memory that call still has to write -- its block, the host range
+    of its delivery.  A page-locked array handed back by a finalizer thread, or another block, while
+    a pipeline sits between its deferred call and lbl_finish_deferred must not make the heavy gas
+    add (and stream its copies) before the other gases have added."""
+    from ctypes import byref, c_void_p
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CO2", 1., 260., num_lines=20000, seed=15, tips_range=(150, 400))
+    heavy = e.load(table)
+    atmos = synthetic.standard_atmosphere(2)
+    v0, vn, npv = 1, 241, 500
+    n = (vn - v0)*npv
+
+    def keep_back(block, target):
+        e.fill_zero(block, asynchronous=True)
+        e.compute(heavy, atmos.t, atmos.p, atmos.vmr["CO2"], v0, vn, npv, remove_pedestal=True,
+                  out=block, scale_density=True, accumulate=True, asynchronous=True,
+                  deliver=target, pieces=2, defer_finish=True)
+        assert e.deferred()
+
+    block, other = DeviceSpectra(e, 2, n), DeviceSpectra(e, 2, n)
+    # page-locked memory straight from the C ABI (host_array()'s pool would keep it)
+    mine, unrelated = c_void_p(), c_void_p()
+    assert e.lib.lbl_host_alloc(e.handle, 2*n*8, byref(mine)) == 0
+    assert e.lib.lbl_host_alloc(e.handle, 1 << 20, byref(unrelated)) == 0
+    from ctypes import c_double
+    target = np.frombuffer((c_double*(2*n)).from_address(mine.value), dtype=np.float64).reshape(2, n)
+    keep_back(block, target)
+    assert e.lib.lbl_host_free(e.handle, unrelated) == 0
+    assert e.deferred()                     # somebody else's array: the deferral stays
+    other.free()
+    assert e.deferred()                     # ... and somebody else's block
+    e.finish_deferred()
+    e.synchronize()
+    want = block.to_host()
+    assert want.any() and np.array_equal(target, want)
+    # the call's own delivery array: finished (and waited for) before the pages go
+    keep_back(block, target)
+    del target
+    assert e.lib.lbl_host_free(e.handle, mine) == 0
+    assert not e.deferred()
+    e.synchronize()
+    assert np.array_equal(block.to_host(), want)
+    # the call's own block
+    again = e.host_array((2, n))
+    keep_back(block, again)
+    block.free()
+    assert not e.deferred()
+    e.synchronize()
+    assert np.array_equal(again, want)
+    e.close()
+
+
+
 def test_compat_entry_device_and_cache(tmp_path):
     """The same-signature entry picks its GPU from LBL_DEVICE / the launcher's local rank,
     re-reads a database file that changed under the same path (the reference re-reads it on
