@@ -1747,8 +1747,23 @@ def run():
             if workers > 1:
                 line["cpu_baseline_parallel"] = cpu_baseline_parallel(
                     tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
+            # "All host cores" = what this process may use: the affinity mask, cut down to the
+            # cgroup's CPU quota where there is one (this pool shows a one-GPU job all 256 hardware
+            # threads of the host and allots it 16 cores' worth of time: 256 processes then share
+            # those, 8.3e9 evals/s against 1.7e10 for 16 -- profiles/bench_r05b.json).
             usable = len(os.sched_getaffinity(0))
-            every = usable if args.cpu_all_cores < 0 else min(args.cpu_all_cores, usable)
+            quota = cpu_quota()
+            if quota is not None:
+                usable = max(1, min(usable, int(round(quota))))
+            every = usable if args.cpu_all_cores < 0 else args.cpu_all_cores
+            if 0 < every <= workers and "cpu_baseline_parallel" in line:
+                line["cpu_baseline_all_cores"] = dict(
+                    line["cpu_baseline_parallel"],
+                    note=f"every core this process may use: affinity mask "
+                         f"{len(os.sched_getaffinity(0))} hardware threads, cgroup CPU quota "
+                         f"{quota} cores -> {usable}; cpu_baseline_parallel's {workers} processes "
+                         f"already use them (the figure is the same run); --cpu-all-cores N forces "
+                         f"a pool of N")
             if every > workers:
                 line["cpu_baseline_all_cores"] = cpu_baseline_parallel(
                     tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, every,

@@ -103,3 +103,52 @@ def test_random_cross_section(seed):
         close(got, expect, f"seed {seed}: {len(bands)} band(s), {levels} level(s)", floor=1e-12)
     finally:
         engine.free_xsec(handle)
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_random_groups_of_continua(continua, continuum_oracle, seed):
+    """lbl_continuum_compute_many on random groups (1-6 continua in random order, one of them
+    possibly twice), random levels and grids -- numpy.arange ones too, whose wavenumbers the
+    kernels form in registers --, writing or adding onto a block: bit for bit what one call per
+    continuum leaves, and within the bar of the sum of the oracle's spectra."""
+    from pylbl_amd.engine import DeviceSpectra
+    rng = np.random.default_rng(11000 + seed)
+    engine = default_engine(0)
+    count = int(rng.integers(1, 7))
+    owners = [OWNERS[i] for i in rng.permutation(len(OWNERS))[:count]]
+    if rng.random() < 0.2:
+        owners.append(owners[0])
+    if rng.random() < 0.4:
+        lower = float(np.round(rng.uniform(-100., 30000.), 2))
+        step = float(rng.choice([0.001, 0.01, 0.05, 0.25, 1., 7.3]))
+        grid = np.arange(lower, lower + step*int(10**rng.uniform(0., 4.8)), step)
+        if grid.size < 2:
+            grid = np.arange(lower, lower + 3*step, step)
+    else:
+        grid = random_grid(rng)
+    levels = int(rng.integers(1, 10))
+    t = rng.uniform(50., 1000., levels)
+    p = 10.**rng.uniform(-2., 6.7, levels)
+    vmr = {name: 10.**rng.uniform(-9., -0.3, levels) for name in
+           ("H2O", "CO2", "O3", "N2O", "CO", "CH4", "O2", "N2")}
+    members = [continua[owner] for owner in owners]
+    adding = rng.random() < 0.5
+    padded = grid.size + int(rng.integers(0, 40))
+    one_by_one, together = DeviceSpectra(engine, levels, padded), DeviceSpectra(engine, levels, padded)
+    if adding:
+        for block in (one_by_one, together):
+            continua["O3"].spectra_levels(t, p, vmr, grid, out=block)
+    for i, continuum in enumerate(members):
+        continuum.spectra_levels(t, p, vmr, grid, out=one_by_one, accumulate=adding or i > 0,
+                                 asynchronous=True)
+    mt_ckd.spectra_levels_many(members, t, p, vmr, grid, together, accumulate=adding,
+                               asynchronous=True)
+    engine.synchronize()
+    a, b = one_by_one.to_host()[:, :grid.size], together.to_host()[:, :grid.size]
+    one_by_one.free()
+    together.free()
+    assert np.array_equal(a, b, equal_nan=True), f"seed {seed}: {owners}, {levels} level(s)"
+    expect = sum(np.stack([continuum_oracle.continuum(owner).spectra(
+        t[i], p[i], {k: v[i] for k, v in vmr.items()}, grid) for i in range(levels)])
+        for owner in owners + (["O3"] if adding else []))
+    close(b, expect, f"seed {seed}: group {owners} adding={adding}", floor=1e-12)
