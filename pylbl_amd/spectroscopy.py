@@ -39,6 +39,22 @@ _FORMULAE = {"water_vapor": "H2O", "carbon_dioxide": "CO2", "ozone": "O3",
              "oxygen": "O2", "nitrogen": "N2"}
 
 
+_XARRAY = []
+
+
+def _optional_xarray():
+    """The xarray module, or None where it is not installed -- looked for ONCE: a failed import
+    walks every entry of sys.path again (60 us per compute_absorption call, behind its last wait:
+    profiles/r05_perf_api_profile.txt)."""
+    if not _XARRAY:
+        try:
+            import xarray
+            _XARRAY.append(xarray)
+        except ImportError:
+            _XARRAY.append(None)
+    return _XARRAY[0]
+
+
 class Atmosphere(object):
     """Pressure, temperature and gas mole fractions as numpy arrays.
 
@@ -554,13 +570,13 @@ class Spectroscopy(object):
             variables = {"absorption": parts[0] if len(parts) == 1 else sum(parts)} \
                 if parts else {}
             extra = {}
-        try:
-            from xarray import DataArray, Dataset
-        except ImportError:
+        xarray = _optional_xarray()
+        if xarray is None:
             out = {"wavenumber": self.grid}
             out.update(extra)
             out.update(variables)
             return out
+        DataArray, Dataset = xarray.DataArray, xarray.Dataset
         data_vars = {"wavenumber": DataArray(self.grid, dims=("wavenumber",),
                                              attrs={"units": "cm-1"})}
         for key, value in extra.items():
