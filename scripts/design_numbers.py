@@ -98,11 +98,16 @@ out.append("| CPU: reference C, 1 thread (%s), whole grid | %.3g | %.1f s | — 
                                                      sp["read_and_line_scalars_s"], 100*sp["read_fraction"],
                                                      sp["voigt_loop_s"]))
 cp, ca = d["cpu_baseline_parallel"], d["cpu_baseline_all_cores"]
-out.append("| CPU: C restatement, 16 processes / %d processes (every hardware thread in the affinity mask) | "
-           "%.3g / %.3g | — | — | the pool allots one GPU 16 of the host's 256 threads: 256 processes share "
-           "that time (cgroup quota reported: %s cores; pool start %.0f s, untimed) |" % (
-               ca["cores"], cp["value"], ca["value"] or 0., ca.get("cgroup_cpu_quota_cores"),
-               ca.get("pool_start_s", 0.)))
+if ca["cores"] == cp["cores"]:
+    out.append("| CPU: C restatement, %d processes = every core the job may use (`cpu_baseline_parallel` = "
+               "`cpu_baseline_all_cores`) | %.3g | — | — | affinity mask %s hardware threads, cgroup CPU quota "
+               "%s cores; forced to 256 processes (`--cpu-all-cores 256`, `profiles/bench_r05b.json`): 8.3e9 — "
+               "they share the 16 cores' time |" % (cp["cores"], cp["value"], cp.get("usable_hardware_threads"),
+                                                   cp.get("cgroup_cpu_quota_cores")))
+else:
+    out.append("| CPU: C restatement, 16 processes / %d processes | %.3g / %.3g | — | — | cgroup CPU quota %s "
+               "cores (pool start %.0f s, untimed) |" % (ca["cores"], cp["value"], ca["value"] or 0.,
+                                                         ca.get("cgroup_cpu_quota_cores"), ca.get("pool_start_s", 0.)))
 ing = d["ingest"]
 out.append("| ingest per molecule (H2O 110 k / CO2 400 k lines): SQLite → arrays (any of the three routes) / "
            "upload / C entry's first call − second | — | %.2f / %.2f s; %.1f / %.1f ms; %.0f / %.0f ms | — | "
