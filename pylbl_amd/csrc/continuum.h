@@ -283,11 +283,18 @@ struct GridForm
     double start, step;
 };
 
+// (double)i for a grid index: grids have fewer than 2^31 points (lbl_grid_load), and a 32-bit
+// conversion is one instruction where the 64-bit one is a dozen.
+__device__ __forceinline__ double index_as_double(long long i)
+{
+    return (double)(int)i;
+}
+
 __device__ __forceinline__ double wavenumber_at(const GridForm & form, long long i)
 {
     if (form.arithmetic)
     {
-        const double offset = (double)i*form.step;      // (product rounded, then the sum)
+        const double offset = index_as_double(i)*form.step;     // (product rounded, then the sum)
         return form.start + offset;
     }
     return form.wavenumber[i];
@@ -303,7 +310,7 @@ __device__ __forceinline__ void load_wavenumbers(const GridForm & form, long lon
         for (int p = 0; p < PT; ++p)
         {
             const long long i = index(p);
-            const double offset = (double)i*form.step;
+            const double offset = index_as_double(i)*form.step;
             x[p] = i < n ? form.start + offset : __builtin_nan("");
         }
         return;
@@ -350,24 +357,101 @@ __device__ __forceinline__ int interval_of(const Band & b, int last, double x, b
     return at;
 }
 
-// One band's contribution for PT points x LV levels of a thread: total[p][l] += 100 * interp.
-// `row` = offset of the band's coarse spectrum of the first of the thread's levels; a level's
-// spectra are `level_points` doubles apart.  Returns false when the whole wavefront lies outside
-// the band (nothing was read).
-template <int PT, int LV>
+// The run of consecutive grid points a wavefront holds (G points per thread: 64 G points, lane l
+// holding points 2l, 2l + 1 of every 128 of them): the wavenumbers of its first and last point.  `usable`: the grid is arithmetic with a positive step (x rises with the
+// index) and the whole run lies inside the grid.
+struct WaveRun
+{
+    double lo, hi;
+    bool usable;
+};
+
+// Grid index of point p of this thread (see WaveRun).
+template <int G>
+__device__ __forceinline__ long long wave_point(long long block_first, int p)
+{
+    if (G == 1) return block_first + threadIdx.x;
+    return block_first + (long long)G*(threadIdx.x & ~63) + (p >> 1)*128 + 2*(threadIdx.x & 63) +
+           (p & 1);
+}
+
+template <int G>
+__device__ __forceinline__ WaveRun wave_run(const GridForm & form, long long n, long long block_first)
+{
+    const long long first = block_first + (long long)G*(threadIdx.x & ~63);
+    const long long last = first + 64*G - 1;
+    WaveRun run;
+    run.usable = form.arithmetic != 0 && form.step > 0. && last < n;
+    run.lo = run.usable ? wavenumber_at(form, first) : 0.;
+    run.hi = run.usable ? wavenumber_at(form, last) : 0.;
+    return run;
+}
+
+// One band's contribution for G points (a pair of neighbours, or one point) x LV levels of a
+// thread: total[p][l] += 100 * interp.  `row` = offset of the band's coarse spectrum of the first of
+// the thread's levels; a level's spectra are `level_points` doubles apart.  Returns false when the
+// whole wavefront lies outside the band (nothing was read).
+//
+// Round 5: on a fine grid a wavefront's run of 64 G points is far narrower than a coarse interval
+// (0.13-0.26 cm-1 against 2-10 cm-1), so the interval is looked for at the run's two ENDS -- the search
+// result is the largest j with xp[j] <= x, non-decreasing in x, and x rises with the index on an
+// arithmetic grid -- and where both ends give the same j every point of the run has it: what is left
+// per point is x - xp[j], the knot test and slope*dx + f with f and slope arriving by scalar loads
+// (8 vector instructions per point and band where the search per point took ~45).  Runs that hold
+// a knot or a band edge take the search per point as before; the values are the same expressions on
+// the same operands either way.
+template <int G, int LV>
 __device__ __forceinline__ bool add_band(const Band & b, const double * __restrict__ coarse,
                                          const double * __restrict__ slopes, long long row,
-                                         long long level_points, int count, const double (&x)[PT],
-                                         double (&total)[PT][LV])
+                                         long long level_points, int count, const double (&x)[G],
+                                         const WaveRun & run, double (&total)[G][LV])
 {
     const int last = b.size - 1;
     const double x_last = b.lower + (double)last*b.resolution;
-    int j[PT];
-    double dx[PT];
-    bool inside[PT], on_knot[PT];
+    if (run.usable)
+    {
+        if (run.hi < b.lower || run.lo > x_last) return false;      // the whole run lies outside
+        if (run.lo >= b.lower && run.hi <= x_last)
+        {
+            // (the run's last point has the interval of its first iff it lies below the next knot)
+            double xj;
+            const int j_lo = interval_of(b, last, run.lo, true, xj);
+            const double next_knot = b.lower + (double)(j_lo + 1)*b.resolution;
+            if (j_lo == last || run.hi < next_knot)
+            {
+                const int j = __builtin_amdgcn_readfirstlane(j_lo);
+                const bool last_knot = j == last;
+#pragma unroll
+                for (int l = 0; l < LV; ++l)
+                {
+                    const long long at = row + (long long)(l < count ? l : 0)*level_points + j;
+                    const double f = coarse[at];
+                    const double slope = slopes[at];
+#pragma unroll
+                    for (int p = 0; p < G; ++p)
+                    {
+                        const bool on_knot = last_knot || xj == x[p];
+                        double value = on_knot ? f : slope*(x[p] - xj) + f;
+                        if (value != value && !on_knot && l < count)
+                        {
+                            const double xn = b.lower + (double)(j + 1)*b.resolution;
+                            const double fn = coarse[at + 1];
+                            value = slope*(x[p] - xn) + fn;
+                            if (value != value && f == fn) value = f;
+                        }
+                        total[p][l] += value*100.;                  // utils.py:171-173
+                    }
+                }
+                return true;
+            }
+        }
+    }
+    int j[G];
+    double dx[G];
+    bool inside[G], on_knot[G];
     bool any = false;
 #pragma unroll
-    for (int p = 0; p < PT; ++p)
+    for (int p = 0; p < G; ++p)
     {
         inside[p] = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
         double xj;
@@ -377,9 +461,9 @@ __device__ __forceinline__ bool add_band(const Band & b, const double * __restri
         any = any || inside[p];
     }
     if (__ballot(any) == 0ull) return false;            // the whole wavefront lies outside
-    double f[PT][LV], slope[PT][LV];
+    double f[G][LV], slope[G][LV];
 #pragma unroll
-    for (int p = 0; p < PT; ++p)
+    for (int p = 0; p < G; ++p)
     {
 #pragma unroll
         for (int l = 0; l < LV; ++l)
@@ -390,7 +474,7 @@ __device__ __forceinline__ bool add_band(const Band & b, const double * __restri
         }
     }
 #pragma unroll
-    for (int p = 0; p < PT; ++p)
+    for (int p = 0; p < G; ++p)
     {
 #pragma unroll
         for (int l = 0; l < LV; ++l)
@@ -419,18 +503,20 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
                                                                double * __restrict__ out,
                                                                long long level_stride, int accumulate)
 {
-    // Points of a thread: pairs of neighbours (one 16-byte access where alignment allows),
-    // pairs 512 apart.  point_index(p) for p = 0..PT-1.
+    // Points of a thread: pairs of neighbours (one 16-byte access where alignment allows), the
+    // lanes' pairs side by side (a store instruction of the wavefront writes 1 KB of consecutive
+    // points), a thread's pairs 128 points apart: a wavefront holds ONE run of 64 PT consecutive
+    // points.  point_index(p) for p = 0..PT-1.
     static_assert(kInterpPoints == 1 || kInterpPoints % 2 == 0, "points come in pairs");
     const long long block_first = (long long)blockIdx.x*(256*kInterpPoints);
     auto point_index = [&](int p) -> long long {
-        return kInterpPoints == 1 ? block_first + threadIdx.x
-                                  : block_first + (p >> 1)*512 + 2*threadIdx.x + (p & 1);
+        return wave_point<kInterpPoints>(block_first, p);
     };
     const int level0 = blockIdx.y*kInterpLevels;
     const int count = min(kInterpLevels, n_levels - level0);
     double x[kInterpPoints];
     load_wavenumbers<kInterpPoints>(form, n, point_index, x);
+    const WaveRun run = wave_run<kInterpPoints>(form, n, block_first);
     double total[kInterpPoints][kInterpLevels], before[kInterpPoints][kInterpLevels];
 #pragma unroll
     for (int l = 0; l < kInterpLevels; ++l)
@@ -456,7 +542,7 @@ __global__ __launch_bounds__(256) void continuum_interp_kernel(BandSet set,
         const Band & b = set.band[k];
         add_band<kInterpPoints, kInterpLevels>(
             b, coarse, slopes, (long long)level0*set.coarse_points + b.spectrum,
-            set.coarse_points, count, x, total);
+            set.coarse_points, count, x, run, total);
     }
 #pragma unroll
     for (int l = 0; l < kInterpLevels; ++l)
@@ -520,42 +606,10 @@ __global__ __launch_bounds__(256) void group_band_spectra_kernel(const GroupBand
     slopes[at] = slope;
 }
 
-// Where a thread's points lie in one band: the interval index, the distance to its lower knot and
-// two bit masks over the points (bit p: inside the band / on a knot).
-template <int PT>
-struct BandPlace
-{
-    int j[PT];
-    double dx[PT];
-    unsigned inside, on_knot;
-};
-
-template <int PT>
-__device__ __forceinline__ void locate_in_band(const Band & b, const double (&x)[PT],
-                                               BandPlace<PT> & place)
-{
-    const int last = b.size - 1;
-    const double x_last = b.lower + (double)last*b.resolution;
-    place.inside = place.on_knot = 0u;
-#pragma unroll
-    for (int p = 0; p < PT; ++p)
-    {
-        const bool inside = (x[p] >= b.lower) && (x[p] <= x_last);   // zero outside; false for NaN
-        double xj;
-        const int at = interval_of(b, last, x[p], inside, xj);
-        place.j[p] = at;
-        place.dx[p] = x[p] - xj;
-        if (inside) place.inside |= 1u << p;
-        if (at == last || xj == x[p]) place.on_knot |= 1u << p;
-    }
-}
-
 // grid = (points / (256 PT), levels / LV).  out[level][i] (+)= sum over the group's continua.
-// The bands are taken NB at a time: the intervals of NB bands are found first, then the table
-// values of all of them are requested together and only then used -- one band after the other
-// (add_band) put the two dependent L2 round trips of every band end to end: 59 us for three
-// continua at 5 M points, where one continuum alone takes 26.
-template <int PT, int LV, int NB>
+// (Taking the bands two to four at a time -- their table values requested together -- was
+// measured and only cost registers: profiles/r05_perf_continuum_group.txt.)
+template <int PT, int LV>
 __global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __restrict__ bands,
                                                            int n_bands, int level_points,
                                                            const double * __restrict__ coarse,
@@ -567,13 +621,13 @@ __global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __r
     static_assert(PT == 1 || PT % 2 == 0, "points come in pairs");
     const long long block_first = (long long)blockIdx.x*(256*PT);
     auto point_index = [&](int p) -> long long {
-        return PT == 1 ? block_first + threadIdx.x
-                       : block_first + (p >> 1)*512 + 2*threadIdx.x + (p & 1);
+        return wave_point<PT>(block_first, p);
     };
     const int level0 = blockIdx.y*LV;
     const int count = min(LV, n_levels - level0);
     double x[PT];
     load_wavenumbers<PT>(form, n, point_index, x);
+    const WaveRun run = wave_run<PT>(form, n, block_first);
     double sum[PT][LV], total[PT][LV];
 #pragma unroll
     for (int l = 0; l < LV; ++l)
@@ -610,71 +664,13 @@ __global__ __launch_bounds__(256) void group_interp_kernel(const GroupBand * __r
         }
         started = true;
     };
-    for (int k0 = 0; k0 < n_bands; k0 += NB)
+    for (int k = 0; k < n_bands; ++k)
     {
-        BandPlace<PT> place[NB];
-        bool wanted[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-        {
-            wanted[q] = false;
-            place[q].inside = place[q].on_knot = 0u;
-            if (k0 + q < n_bands)
-            {
-                locate_in_band<PT>(bands[k0 + q].band, x, place[q]);
-                wanted[q] = __ballot(place[q].inside != 0u) != 0ull;   // wave-uniform
-            }
-        }
-        double f[NB][PT][LV], slope[NB][PT][LV];
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-        {
-            if (!wanted[q]) continue;
-            const long long row = (long long)level0*level_points + bands[k0 + q].band.spectrum;
-#pragma unroll
-            for (int p = 0; p < PT; ++p)
-            {
-#pragma unroll
-                for (int l = 0; l < LV; ++l)
-                {
-                    const long long at = row + (long long)(l < count ? l : 0)*level_points +
-                                         place[q].j[p];
-                    f[q][p][l] = coarse[at];
-                    slope[q][p][l] = slopes[at];
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-        {
-            if (k0 + q >= n_bands) continue;
-            const GroupBand * gb = bands + (k0 + q);        // wave-uniform: scalar loads
-            if (k0 + q > 0 && gb->first_of_owner) fold();
-            if (!wanted[q]) continue;
-            const Band & b = gb->band;
-            const long long row = (long long)level0*level_points + b.spectrum;
-#pragma unroll
-            for (int p = 0; p < PT; ++p)
-            {
-                const bool inside = (place[q].inside >> p) & 1u;
-                const bool on_knot = (place[q].on_knot >> p) & 1u;
-#pragma unroll
-                for (int l = 0; l < LV; ++l)
-                {
-                    double value = on_knot ? f[q][p][l]
-                                           : slope[q][p][l]*place[q].dx[p] + f[q][p][l];
-                    if (value != value && inside && !on_knot && l < count)
-                    {
-                        const long long at = row + (long long)l*level_points + place[q].j[p];
-                        const double xn = b.lower + (double)(place[q].j[p] + 1)*b.resolution;
-                        const double fn = coarse[at + 1];
-                        value = slope[q][p][l]*(x[p] - xn) + fn;
-                        if (value != value && f[q][p][l] == fn) value = f[q][p][l];
-                    }
-                    if (inside) total[p][l] += value*100.;         // utils.py:171-173
-                }
-            }
-        }
+        const GroupBand * gb = bands + k;           // wave-uniform: scalar loads
+        if (k > 0 && gb->first_of_owner) fold();
+        add_band<PT, LV>(gb->band, coarse, slopes,
+                         (long long)level0*level_points + gb->band.spectrum, level_points, count, x,
+                         run, total);
     }
     fold();
 #pragma unroll

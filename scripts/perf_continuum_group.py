@@ -17,9 +17,9 @@ from pylbl_amd.engine import DeviceSpectra, Engine      # noqa: E402
 
 engine = Engine(0)
 cases = (("3 continua, 1 level, 5 M points", ("H2OForeign", "H2OSelf", "CO2"), 1,
-          np.arange(1., 5000., 0.001), (121, 141)),
+          np.arange(1., 5000., 0.001), (121, 141, 181)),
          ("6 continua, 1 level, 5 M points", ("H2OForeign", "H2OSelf", "CO2", "O3", "O2", "N2"), 1,
-          np.arange(1., 5000., 0.001), (121, 141)),
+          np.arange(1., 5000., 0.001), (121, 141, 181)),
          ("4 continua, 16 levels, 3 M points", ("H2OForeign", "H2OSelf", "CO2", "O3"), 16,
           np.arange(1., 3000., 0.001), (124, 122, 142)))
 for label, owners, levels, grid, shapes in cases:
