@@ -178,7 +178,13 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
  * 0), "aligned_tiles" (0/1: cell-aligned tiles also without the far-field series), "lanes" (0, 2..8:
  * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "small_points" (grids of
  * up to so many points x levels count as short calls), "graphs" (0/1: short calls replay a HIP
- * graph of their kernels; default 0), "ablate" (timing diagnostics only). */
+ * graph of their kernels; default 0: it costs the host more than the launches, bench.py's
+ * small_grid_options.config0.graph_replay_option), "chain_first" (0/1: a far-field call queues its
+ * pedestal chain in front of its accumulate launches; measured +-0, default 0), "interp_shape"
+ * (experiments: shape of the continuum interpolation kernels, 10 PT + LV for one continuum,
+ * 100 + 10 PT + LV for groups; 0 = by the number of levels), "item_floor" (experiments: fewest lines
+ * per work item), "ablate" (timing diagnostics only: results are wrong; refused from
+ * $PYLBL_AMD_OPTIONS). */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
 /* With option timing=1 (or 2): accumulated kernel milliseconds and launch counts since the last
