@@ -395,6 +395,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->chain_first = (int)value;
     }
+    else if (key == "item_order" && (value == 0 || value == 1))
+    {
+        engine->item_order = (int)value;
+    }
     else if (key == "item_floor" && value >= 0 && value <= 65536)
     {
         engine->item_floor = (int)value;
