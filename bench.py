@@ -21,7 +21,7 @@ every rank gets --levels-per-gpu levels (default 1).
 Besides the contract's keys the line carries (N = 1): `roofline` (the resource that binds the
 dominant kernel: the fp64 vector ALU), `roofline_hbm_algorithmic` (SURVEY 8d's 24 B/eval figure,
 for the record), `cpu_baseline` (+ `_parallel`), and untimed legs that measure what users run:
-`sustained`, `lane_overlap_option`, `pedestal_option`, `standard_atmosphere_option`,
+`sustained`, `single_lane_option`, `pedestal_option`, `standard_atmosphere_option`,
 `banded_table_option`, `dense_table_option`,
 `small_grid_options`, `farfield_option`, `api_call`, `continuum_slot`, `cross_section_slot`,
 the other BASELINE configs at one GPU's size -- `config2_option` (8 molecules, 5 M points),
@@ -1427,13 +1427,13 @@ def run():
                 issue["frac_of_issue_slots_at_measured_clock"] = \
                     per_simd/issue["gui_active_cycles_per_xcd"]
             line["roofline"]["issue"] = issue
-        if (args.pedestal or n*levels_local <= (1 << 20) or args.farfield) and \
-                not args.host_output and launches[2] > 0:
-            # Calls with a pedestal pass, on grids of at most 2^20 points x levels, or with the
-            # far-field series alternate between engine lanes: their accumulate kernels overlap in
-            # time, and an event-timed launch is stretched by its neighbour.  The fraction is
-            # therefore taken from the same launches run alone (blocking calls, one lane), outside
-            # the timed region; what the events read inside it is kept beside it.
+        if not args.host_output and launches[2] > 0:
+            # Asynchronous calls that leave their spectra in HBM take turns on the engine's lanes:
+            # the tail of one accumulate grid and the head of the next overlap in time, and an
+            # event-timed launch is stretched by its neighbour.  The fraction is therefore taken
+            # from the same launches run alone (blocking calls, one lane), outside the timed
+            # region; what the events read inside it is kept beside it, and so is the fraction
+            # that follows from the step time alone (every kernel of the step in the denominator).
             from pylbl_amd.engine import DeviceSpectra
             engine.set_option("timing", 2)
             engine.timing(reset=True)
@@ -1452,12 +1452,19 @@ def run():
                 "achieved": alone_tflops, "frac": alone_tflops/FP64_VECTOR_PEAK_TFLOPS,
                 "avg_launch_ms": alone, "launches_timed": alone_launches[2],
                 "avg_launch_ms_overlapped_in_step": accumulate_ms,
-                "frac_from_overlapped_launches": tflops/FP64_VECTOR_PEAK_TFLOPS})
+                "frac_from_overlapped_launches": tflops/FP64_VECTOR_PEAK_TFLOPS,
+                "frac_from_step_time": (evals_per_step_local*FLOPS_PER_EVAL/(ms_per_step*1e-3)
+                                        / 1e12/FP64_VECTOR_PEAK_TFLOPS)})
             line["roofline"]["note"] += (
-                "; the calls of this run alternate between engine lanes (pedestal pass, small grid or "
-                "far-field series) and their accumulate kernels overlap, so achieved / frac / "
-                "avg_launch_ms come from the same launches run alone after the timed region "
-                "(blocking calls); avg_launch_ms_overlapped_in_step is what the events read inside it")
+                "; the calls of the timed region take turns on two (with a pedestal pass: four) "
+                "engine lanes, so that the tail of one accumulate grid runs beside the next call's "
+                "prologue and the head of its grid: ms_per_step is SHORTER than the sum of the "
+                "launches run alone.  achieved / frac / avg_launch_ms come from the same launches "
+                "run alone after the timed region (blocking calls on one lane: what rocprofv3 shows "
+                "for a launch that has the chip to itself); avg_launch_ms_overlapped_in_step is "
+                "what the events read inside the region (two grids side by side), and "
+                "frac_from_step_time = 7 flops x evals_per_step / ms_per_step / peak, which needs "
+                "no launch taken alone")
         if args.farfield:
             # The series replaces most evaluations by one polynomial per point: "7 flops per eval x
             # evals" is not what the kernel executes, and the quotient is not a fraction of a peak.
@@ -1483,20 +1490,19 @@ def run():
                 remove_pedestal=args.pedestal, min_seconds=2.,
                 label="the timed step repeated for >= 2 s (clocks at their sustained level)")
         if leg("overlap") and not args.pedestal and args.config == "target":
-            # The timed step queues its plain calls back to back on one stream (a launch then takes
-            # what it takes alone, which is what `roofline` divides by).  Letting them take turns on
-            # two lanes like the calls with a pedestal do -- the next call's prologue and the tail of
-            # this one's accumulate grid overlap -- is an engine option (small_points): the same step
-            # that way, for the record.
-            engine.set_option("small_points", 1 << 30)
+            # The timed step's plain calls take turns on two lanes (the next call's prologue and the
+            # head of its accumulate grid beside the tail of this one's).  The same step with the
+            # calls back to back on one stream (engine option overlap_plain = 0: every launch has
+            # the chip to itself, as the launches `roofline` divides by), for the record.
+            engine.set_option("overlap_plain", 0)
             try:
-                line["lane_overlap_option"] = lines_leg(
+                line["single_lane_option"] = lines_leg(
                     engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
                     remove_pedestal=False, ring=2,
-                    label="the timed step with its calls taking turns on two lanes "
-                          "(engine option small_points = 2^30), two sets of output blocks")
+                    label="the timed step with its calls back to back on one lane "
+                          "(engine option overlap_plain = 0), two sets of output blocks")
             finally:
-                engine.set_option("small_points", 1 << 20)
+                engine.set_option("overlap_plain", 1)
         if leg("pedestal") and not args.pedestal:
             line["pedestal_option"] = lines_leg(
                 engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,

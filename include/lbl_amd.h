@@ -176,7 +176,10 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
  * lbl_compute_streamed avoids the internal streams that share a hardware queue with the copy
  * stream; default 1), "farfield" (0/1: distant lines by power series, default
  * 0), "aligned_tiles" (0/1: cell-aligned tiles also without the far-field series), "lanes" (0, 2..8:
- * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "small_points" (grids of
+ * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "overlap_plain" (0/1:
+ * plain asynchronous calls on grids larger than small_points take turns on two lanes like the
+ * others, so that one call's last workgroups run beside the next call's first; default 1; 0: back
+ * to back on the first stream), "small_points" (grids of
  * up to so many points x levels count as short calls), "graphs" (0/1: short calls replay a HIP
  * graph of their kernels; default 0: it costs the host more than the launches, bench.py's
  * small_grid_options.config0.graph_replay_option), "chain_first" (0/1: a far-field call queues its
@@ -198,8 +201,9 @@ int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t reset);
 
 /* The engine's first HIP stream (a hipStream_t), for callers that time with their own events.
- * Plain calls run on it back to back; asynchronous calls with remove_pedestal rotate over
- * several streams, so events on this one do not bracket them (use lbl_synchronize / lbl_timing). */
+ * Blocking calls run on it back to back; asynchronous calls into device memory rotate over
+ * several streams, so events on this one do not bracket them (use lbl_synchronize / lbl_timing,
+ * or lbl_order_stream_after_engine in front of the caller's own event). */
 void *lbl_stream(lbl_engine *engine);
 
 /* Sharing HBM blocks with another HIP user of the same device without stopping the host (the

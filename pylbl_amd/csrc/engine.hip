@@ -34,6 +34,7 @@
 
 #include "engine_core.h"
 #include "lanes_plans.inc"
+#include "compute_stages.inc"
 #include "compute_call.inc"
 
 // (calibrate_delivery_lanes, used by lbl_engine_create)
@@ -406,6 +407,10 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     else if (key == "graphs" && (value == 0 || value == 1))
     {
         engine->graphs = (int)value;
+    }
+    else if (key == "overlap_plain" && (value == 0 || value == 1))
+    {
+        engine->overlap_plain = (int)value;
     }
     else if (key == "small_points" && value >= 0)
     {

@@ -432,7 +432,8 @@ struct lbl_engine
     int item_order = 1;             // 0: items by exact weight; 1: by weight class, grid order within
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
-    long long small_points = 1ll << 20;    // grids (points x levels) up to this size rotate too
+    long long small_points = 1ll << 20;    // grids (points x levels) up to this size count as small
+    int overlap_plain = 1;          // plain asynchronous calls on larger grids take turns on two lanes too
     int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
     int skip_delivery_lanes = 1;    // delivering calls avoid lanes that share the copy stream's queue
     int chain_first = 0;            // 1: far-field calls queue the pedestal chain before the accumulate launches (+-0)

@@ -17,9 +17,10 @@ rows = [
     ("**default (target): 1 level, H2O+CO2, 5 M points, `remove_pedestal=False`**", d["value"],
      d["ms_per_step"], d["spectra_per_s"],
      "frac **%.2f** (%.2f ms per launch)" % (d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])),
-    ("same for ≥ 2 s (`sustained`) / calls on two lanes (`lane_overlap_option`)",
+    ("same for ≥ 2 s (`sustained`) / calls back to back on one lane (`single_lane_option`)",
      d["sustained"]["value"], d["sustained"]["ms_per_step"], d["sustained"]["spectra_per_s"],
-     "%.3g on two lanes" % d["lane_overlap_option"]["value"]),
+     "%.3g on one lane; frac from the step time %.2f" % (
+         d["single_lane_option"]["value"], d["roofline"].get("frac_from_step_time", float("nan")))),
     ("same, `remove_pedestal=True` — what `compute_absorption` defaults to (`pedestal_option`)",
      d["pedestal_option"]["value"], d["pedestal_option"]["ms_per_step"],
      d["pedestal_option"]["spectra_per_s"], ""),

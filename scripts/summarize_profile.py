@@ -21,6 +21,28 @@ for row in csv.DictReader(open(stats)):
         "calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"])/1e6,
         "min_ms": float(row["MinNs"])/1e6, "max_ms": float(row["MaxNs"])/1e6,
         "percent": float(row["Percentage"])}
+# Asynchronous calls take turns on two lanes, so most accumulate launches of the timed region run
+# beside the tail or the head of another one; bench.py's `roofline` divides by launches run alone
+# (blocking calls after the region).  The trace tells the two kinds apart: mean duration of the
+# accumulate launches that overlap no other accumulate launch in time, and of those that do.
+traces = glob.glob(f"{src}/stats/*/*_kernel_trace.csv")
+if traces:
+    spans = collections.defaultdict(list)
+    for row in csv.DictReader(open(traces[0])):
+        name = row["Kernel_Name"].split("(")[0]
+        if "accumulate_kernel" in name:
+            spans[name].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+    everything = sorted(s for v in spans.values() for s in v)
+    for name, mine in spans.items():
+        alone, beside = [], []
+        for b, e in mine:
+            others = sum(1 for (b2, e2) in everything if b2 < e and b < e2) - 1
+            (beside if others > 0 else alone).append((e - b)/1e6)
+        summary["kernels"].setdefault(name, {}).update({
+            "launches_alone": len(alone),
+            "avg_ms_alone": sum(alone)/len(alone) if alone else None,
+            "launches_beside_another": len(beside),
+            "avg_ms_beside_another": sum(beside)/len(beside) if beside else None})
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     files = glob.glob(f"{src}/{kind}/*/*_counter_collection.csv")
     if not files:

@@ -32,8 +32,8 @@ def test_pipeline(engine, seed):
     v0 = int(rng.integers(1, 3000))
     span = int(rng.integers(3, max(4, min(60, 600_000//npv))))
     if rng.random() < 0.15:
-        # more than 2^20 points: plain calls then queue on one lane and join the others by events
-        # instead of taking turns on them (engine option small_points)
+        # more than 2^20 points: plain calls take turns on two lanes (engine option overlap_plain;
+        # three up to 2^20 points, small_points)
         npv, span = 1000, int(rng.integers(1060, 1300))
     vn = v0 + span
     n = span*npv
