@@ -1437,9 +1437,12 @@ def run():
             from pylbl_amd.engine import DeviceSpectra
             engine.set_option("timing", 2)
             engine.timing(reset=True)
+            # (3 to 10 launches per molecule: about 50 ms of them, so that the mean does not hang
+            # on one launch's clock)
+            alone_repeats = int(min(10, max(3, 50./max(ms_per_step, 1e-3))))
             for m, levels in plan.by_molecule(rank).items():
                 scratch = DeviceSpectra(engine, len(levels), n)
-                for _ in range(3):
+                for _ in range(alone_repeats):
                     engine.compute(handles[molecules[m]], atmos.t[levels], atmos.p[levels],
                                    vmr[molecules[m]][levels], *grid_args,
                                    remove_pedestal=args.pedestal, out=scratch)
