@@ -1072,6 +1072,516 @@ def main():
         os._exit(3 if late else 1)
 
 
+def first_level(job):
+    """Handles in the workload's order and the first level's T, P and mixing ratios: what the
+    one-level legs compute with."""
+    handle_list = [job.handles[f] for f in job.molecules]
+    vmr1 = {f: job.atmos.vmr[f][:1] for f in job.molecules}
+    return handle_list, job.atmos.t[:1], job.atmos.p[:1], vmr1
+
+
+def lines_option_legs(job, line, leg):
+    """The timed step again under the conditions users meet: for >= 2 s, on one lane, with the
+    pedestal removed, eight levels per call, banded and very dense line tables."""
+    args, engine, tables, molecules = job.args, job.engine, job.tables, job.molecules
+    atmos, grid_args, v_lo, v_hi, workload = job.atmos, job.grid_args, job.v_lo, job.v_hi, job.workload
+    handle_list, t1, p1, vmr1 = first_level(job)
+    from pylbl_amd import synthetic
+    if leg("sustained"):
+        line["sustained"] = lines_leg(
+            engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+            remove_pedestal=args.pedestal, min_seconds=2.,
+            label="the timed step repeated for >= 2 s (clocks at their sustained level)")
+    if leg("overlap") and not args.pedestal and args.config == "target":
+        # The timed step's plain calls take turns on two lanes (the next call's prologue and the
+        # head of its accumulate grid beside the tail of this one's).  The same step with the
+        # calls back to back on one stream (engine option overlap_plain = 0: every launch has
+        # the chip to itself, as the launches `roofline` divides by), for the record.
+        engine.set_option("overlap_plain", 0)
+        try:
+            line["single_lane_option"] = lines_leg(
+                engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+                remove_pedestal=False, ring=2,
+                label="the timed step with its calls back to back on one lane "
+                      "(engine option overlap_plain = 0), two sets of output blocks")
+        finally:
+            engine.set_option("overlap_plain", 1)
+    if leg("pedestal") and not args.pedestal:
+        line["pedestal_option"] = lines_leg(
+            engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+            remove_pedestal=True, ring=2,
+            label="same workload with remove_pedestal=True (the default through "
+                  "compute_absorption, spectroscopy.py:163-164), two sets of output blocks "
+                  "used in turn like the timed step's")
+    if leg("atmosphere"):
+        standard = synthetic.standard_atmosphere(8)
+        line["standard_atmosphere_option"] = lines_leg(
+            engine, handle_list, tables, standard.t, standard.p,
+            {f: standard.vmr[f] for f in molecules}, grid_args, max(args.steps//4, 2),
+            remove_pedestal=True,
+            label="8 standard-atmosphere levels (1013 hPa ... 0.1 hPa) in one batched call "
+                  "per molecule, remove_pedestal=True")
+    if leg("banded") and not args.banded:
+        banded_tables = job.make_tables(True)
+        banded_handles = [engine.load(t) for t in banded_tables]
+        line["banded_table_option"] = lines_leg(
+            engine, banded_handles, banded_tables, t1, p1, vmr1, grid_args, args.steps,
+            remove_pedestal=True,
+            label="same line counts clustered in 8 Gaussian bands per molecule "
+                  "(synthetic.banded_line_table), remove_pedestal=True")
+        for h in banded_handles:
+            engine.free(h)
+    if leg("dense") and args.config == "target":
+        # A table several times denser than the workload's (dozens of pressure-shifted lines
+        # alternate between two windows at every integer wavenumber): the step with and
+        # without the pedestal, whose chain such tables used to send to its serial form.
+        dense = [synthetic.banded_line_table("CO2", v_lo, v_hi, num_lines=1_600_000, bands=8,
+                                             seed=5, inside=True)]
+        dense_handles = [engine.load(t) for t in dense]
+        dense_vmr = {"CO2": atmos.vmr["CO2"][:1]} if "CO2" in atmos.vmr else \
+            {"CO2": np.asarray([3.6e-4])}
+        dense_plain = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
+                          max(args.steps//2, 2), remove_pedestal=False, ring=2,
+                          label="one molecule, 1.6 M lines in 8 Gaussian bands inside the grid "
+                                "(synthetic.banded_line_table(inside=True))")
+        with_pedestal = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
+                                  max(args.steps//2, 2), remove_pedestal=True, ring=2,
+                                  label="the same with remove_pedestal=True")
+        line["dense_table_option"] = {"plain": dense_plain, "remove_pedestal": with_pedestal,
+                                      "lines": int(dense[0].num_lines)}
+        for h in dense_handles:
+            engine.free(h)
+
+
+def small_grid_legs(job, line):
+    """BASELINE configs[0] and [1] as rings of asynchronous calls, and configs[0] as a replayed
+    HIP graph against plain launches."""
+    engine, atmos = job.engine, job.atmos
+    handle_list, t1, p1, vmr1 = first_level(job)
+    from pylbl_amd import synthetic
+    small = {}
+    for name in ("0", "1"):
+        mols, lo, hi, step_cm, _ = CONFIGS[name]
+        ga = synthetic.grid_arguments(np.asarray([lo, lo + step_cm, hi - step_cm]))
+        small_tables = [synthetic.line_table(f, lo, hi) for f in mols]
+        small_handles = [engine.load(t) for t in small_tables]
+        small[f"config{name}"] = lines_leg(
+            engine, small_handles, small_tables, t1, p1,
+            {f: atmos.vmr[f][:1] for f in mols}, ga, 50, min_seconds=0.3, ring=4,
+            label=f"BASELINE configs[{name}]: {'+'.join(mols)}, {lo:g}-{hi:g} cm-1 at "
+                  f"{step_cm:g} cm-1; throughput of asynchronous calls into a ring of 4 "
+                  f"output blocks")
+        if name == "0":
+            # The three-kernel call as a replayed HIP graph (engine option graphs): the
+            # ring of asynchronous calls again, and the blocking call that returns a host
+            # array -- what the reference's caller sees (gas_optics.py:61-91) -- timed call
+            # by call, with the option off and on.
+            entry = small["config0"]
+            x0 = atmos.vmr[mols[0]][:1]
+            entry["graph_replay_option"] = {}
+            for graphs in (0, 1):
+                engine.set_option("graphs", graphs)
+                for _ in range(50):
+                    engine.compute(small_handles[0], t1, p1, x0, *ga)
+                times = []
+                for _ in range(400):
+                    begin = time.perf_counter()
+                    engine.compute(small_handles[0], t1, p1, x0, *ga)
+                    times.append(time.perf_counter() - begin)
+                ring = lines_leg(engine, small_handles, small_tables, t1, p1,
+                                 {f: atmos.vmr[f][:1] for f in mols}, ga, 50,
+                                 min_seconds=0.3, ring=4) if graphs else entry
+                entry["graph_replay_option"]["on" if graphs else "off"] = {
+                    "ring_evals_per_s": ring["value"],
+                    "ring_us_per_call": ring["ms_per_step"]*1e3/len(small_handles),
+                    "blocking_call_us_median": float(np.median(times))*1e6,
+                    "blocking_call_us_min": min(times)*1e6}
+            engine.set_option("graphs", 0)
+            entry["graph_replay_option"]["shipped"] = "off (engine option graphs = 0)"
+        for h in small_handles:
+            engine.free(h)
+    line["small_grid_options"] = small
+
+
+def farfield_legs(job, line):
+    """The step with the far-field series (what Spectroscopy runs by default), with and without
+    the pedestal, each with the issue-slot roofline of its accumulate launches run alone."""
+    args, engine = job.args, job.engine
+    tables, grid_args, workload = job.tables, job.grid_args, job.workload
+    handle_list, t1, p1, vmr1 = first_level(job)
+    engine.set_option("farfield", 1)
+    far = {}
+    for ped in (False, True):
+        key = "remove_pedestal" if ped else "plain"
+        far[key] = lines_leg(
+            engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
+            remove_pedestal=ped)
+        # What the series leaves to be executed point by point is no longer "7 flops x the
+        # closed-form evals": the fraction is the share of the chip's fp64 ISSUE SLOTS the
+        # launch filled -- executed fp64 wave-instructions (PMC pass of this same
+        # workload, profiles/) over the launch's duration here, timed alone.
+        calls = [(h, t1, p1, vmr1[tb.formula], grid_args, {"remove_pedestal": ped})
+                 for h, tb in zip(handle_list, tables)]
+        alone = alone_roofline(engine, calls, far[key]["evals_per_step"], repeats=3)
+        far_workload = workload.replace(
+            "remove_pedestal=False", f"remove_pedestal={ped}") + ", far-field series on"
+        roof = {"bound": "valu_fp64_issue", "unit": "fraction of fp64 issue slots",
+                "kernel": "lbl::accumulate_kernel<8>",
+                "avg_launch_ms": alone["avg_launch_ms"],
+                "accumulate_ms_per_step_alone": alone["accumulate_ms_per_step_alone"],
+                "farfield_series_ms_per_step_alone":
+                    alone["farfield_series_ms_per_step_alone"],
+                "launches_timed": alone["launches_timed"], "frac": None, "traffic": None}
+        issue = issue_slot_fraction(profiled_issue(far_workload), alone["avg_launch_ms"])
+        if issue is not None:
+            roof["issue"] = issue
+            roof["frac"] = issue.get("frac_of_issue_slots_at_measured_clock",
+                                     issue["frac_of_issue_slots_at_2.4GHz"])
+            roof["achieved"], roof["peak"] = roof["frac"], 1.0
+        for kernel in ("farfield_kernel", "farfield_group_kernel"):
+            counted, source = profiled_traffic(far_workload, kernel)
+            if counted is not None:
+                roof.setdefault("series_kernels", {})[kernel] = {
+                    "hbm_bytes_per_launch": counted, "source": f"profiles/{source}"}
+        if "series_kernels" in roof and alone["farfield_series_ms_per_step_alone"] > 0.:
+            moved = sum(v["hbm_bytes_per_launch"] for v in roof["series_kernels"].values())
+            # (one launch of each per molecule call)
+            seconds = alone["farfield_series_ms_per_step_alone"]*1e-3/len(handle_list)
+            roof["series_kernels"]["hbm"] = {
+                "bound": "hbm", "achieved": moved/seconds/1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": moved/seconds/1e9/HBM_PEAK_GBS,
+                "note": "HBM bytes of the two series kernels (PMC) / their duration here"}
+        roof["note"] = (
+            "far-field series on: frac = executed fp64 wave-instructions per "
+            "accumulate_kernel<8> launch (rocprofv3 --pmc pass of this workload, "
+            "profiles/) x 4 cycles / (1024 SIMDs x shader clock x launch duration, HIP "
+            "events, launches run alone); None until a counter summary of this exact "
+            "workload is committed")
+        far[key]["roofline"] = roof
+    engine.set_option("farfield", 0)
+    far["note"] = ("engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 "
+                   "tile half-widths away are summed as one power series per tile "
+                   "(truncation <= ~1.5e-11 relative); same closed-form eval count; "
+                   "parity-tested at the same 1e-6 bar; what Spectroscopy(farfield=True) "
+                   "runs -- remove_pedestal is what a user of compute_absorption() gets "
+                   "by default (spectroscopy.py:163-164); never the headline value")
+    line["farfield_option"] = far
+
+
+def other_config_legs(job, line, leg):
+    """BASELINE configs[2], [3] and [4] at one GPU's size, on the driver-run line."""
+    args, engine, tables = job.args, job.engine, job.tables
+    handles, molecules, grid_args = job.handles, job.molecules, job.grid_args
+    handle_list, t1, p1, vmr1 = first_level(job)
+    from pylbl_amd import distributed, synthetic
+    if args.config == "target" and (leg("config2") or leg("config4")):
+        # The other BASELINE configs at one GPU's size (the eight README molecules on
+        # 1-5000 cm-1 serve configs[2] and configs[4]).
+        eight = [t for t in tables if t.formula in EIGHT]
+        have = {t.formula for t in eight}
+        eight += [synthetic.line_table(f, 1., 5000., scale=args.line_scale)
+                  for f in EIGHT if f not in have]
+        eight.sort(key=lambda t: EIGHT.index(t.formula))
+        eight_handles = [handles[t.formula] if t.formula in handles else engine.load(t)
+                         for t in eight]
+        if leg("config2"):
+            surface = synthetic.surface_level()
+            vmr8 = {f: surface.vmr[f][:1] for f in EIGHT}
+            entry = lines_leg(
+                engine, eight_handles, eight, t1, p1, vmr8, grid_args, max(args.steps//2, 3),
+                remove_pedestal=False,
+                label="BASELINE configs[2]: 1 level, all 8 README molecules "
+                      f"({'+'.join(EIGHT)}), 1-5000 cm-1 at 0.001 cm-1 (5 M points), "
+                      "remove_pedestal=False like the headline")
+            calls = [(h, t1, p1, vmr8[tb.formula], grid_args, {"remove_pedestal": False})
+                     for h, tb in zip(eight_handles, eight)]
+            entry["roofline"] = alone_roofline(engine, calls, entry["evals_per_step"])
+            entry["lines"] = {t.formula: int(t.num_lines) for t in eight}
+            line["config2_option"] = entry
+        if leg("config4"):
+            ga4 = synthetic.grid_arguments(np.asarray([1., 1.0005, 5000. - 0.0005]))
+            rank3 = distributed.level_shard(256, 3, 8)
+            picked = list(range(rank3.start, rank3.stop, 8))        # 96, 104, 112, 120
+            line["config4_share_option"] = share_leg(
+                engine, "4", eight, eight_handles, picked, 256, ga4, "total",
+                max(args.steps//6, 3),
+                label="BASELINE configs[4] (256 levels x 8 molecules, 1-5000 cm-1 at 0.0005 "
+                      "cm-1 = 10 M points, over 8 GPUs): 4 of rank 3's 32 levels "
+                      f"(levels {picked} of the 256-level standard atmosphere) x 8 molecules, "
+                      "remove_pedestal=True, n k summed over the gases on the device "
+                      "(output 'total')")
+        for t, h in zip(eight, eight_handles):
+            if t.formula not in handles:
+                engine.free(h)
+    if args.config == "target" and leg("config3"):
+        mols3, lo3, hi3, dv3, levels3 = CONFIGS["3"]
+        ga3 = synthetic.grid_arguments(np.asarray([lo3, lo3 + dv3, hi3 - dv3]))
+        tables3 = [synthetic.line_table(f, lo3, hi3, scale=args.line_scale) for f in mols3]
+        handles3 = [engine.load(t) for t in tables3]
+        shares = {}
+        for share_rank in (0, 7):
+            block = distributed.level_shard(levels3, share_rank, 8)
+            picked = list(range(block.start, block.stop))
+            shares[share_rank] = share_leg(
+                engine, "3", tables3, handles3, picked, levels3, ga3, "gas",
+                max(args.steps//6, 3),
+                label=f"BASELINE configs[3] (64-level standard atmosphere, {'+'.join(mols3)}, "
+                      f"1-3000 cm-1 at 0.001 cm-1 = 3 M points, levels sharded over 8 GPUs): "
+                      f"rank {share_rank}'s share, levels {picked[0]}-{picked[-1]} "
+                      f"({'1013-330 hPa' if share_rank == 0 else '0.3-0.1 hPa: the slowest share, it bounds the job'}), "
+                      "remove_pedestal=True, one spectrum per gas left in HBM")
+        # The share that bounds the 8-GPU job is the record's entry; rank 0's rides along.
+        line["config3_share_option"] = dict(shares[7], rank0_share=shares[0])
+        for h in handles3:
+            engine.free(h)
+
+
+def api_and_slot_legs(job, line, leg):
+    """Spectroscopy.compute_absorption() as a user calls it, and the continuum and
+    cross-section slots by themselves."""
+    args, engine, tables, molecules, atmos = job.args, job.engine, job.tables, job.molecules, job.atmos
+    v_lo, v_hi, dv, workload, levels_local = job.v_lo, job.v_hi, job.dv, job.workload, job.levels_local
+    if leg("api"):
+        # What the call queues on the device: Spectroscopy sums distant lines through the
+        # far-field series by default and removes the pedestal (continua on).
+        device = line.get("farfield_option", {}).get("remove_pedestal") or \
+            line.get("pedestal_option", line)
+        line["api_call"] = api_leg(engine, tables, atmos, v_lo, v_hi, dv,
+                                   device["ms_per_step"])
+    if leg("continuum"):
+        mine = slice(0, levels_local)
+        extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps,
+                              not args.no_cpu_baseline)
+        if extra is not None:
+            line["continuum_slot"] = extra
+            traffic, source = profiled_traffic(workload, "group_interp_kernel")
+            if traffic is not None:
+                extra["roofline"]["traffic"] = traffic
+                extra["roofline"]["traffic_source"] = f"profiles/{source}"
+        extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps,
+                                  not args.no_cpu_baseline)
+        line["cross_section_slot"] = extra
+        traffic, source = profiled_traffic(workload, "xsec_interp_kernel")
+        if traffic is not None:
+            extra["roofline"]["traffic"] = traffic
+            extra["roofline"]["traffic_source"] = f"profiles/{source}"
+
+
+def cpu_legs(job, line, shared_db):
+    """The CPU baselines timed on this box's host cores: the reference's own C on one thread,
+    the C restatement on 16 processes, and on every core the process may use."""
+    args, tables, atmos, molecules = job.args, job.tables, job.atmos, job.molecules
+    grid_v0, grid_vn, n_per_v = job.grid_args
+    v_lo, v_hi = job.v_lo, job.v_hi
+    db = shared_db
+    line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, grid_vn, n_per_v,
+                                        args.cpu_sample_cm, args.pedestal, db=db)
+    workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
+    if workers > 1:
+        line["cpu_baseline_parallel"] = cpu_baseline_parallel(
+            tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
+    # "All host cores" = what this process may use: the affinity mask, cut down to the
+    # cgroup's CPU quota where there is one (this pool shows a one-GPU job all 256 hardware
+    # threads of the host and allots it 16 cores' worth of time: 256 processes then share
+    # those, 8.3e9 evals/s against 1.7e10 for 16 -- profiles/bench_r05b.json).
+    usable = len(os.sched_getaffinity(0))
+    quota = cpu_quota()
+    if quota is not None:
+        usable = max(1, min(usable, int(round(quota))))
+    every = usable if args.cpu_all_cores < 0 else args.cpu_all_cores
+    if 0 < every <= workers and "cpu_baseline_parallel" in line:
+        line["cpu_baseline_all_cores"] = dict(
+            line["cpu_baseline_parallel"],
+            note=f"every core this process may use: affinity mask "
+                 f"{len(os.sched_getaffinity(0))} hardware threads, cgroup CPU quota "
+                 f"{quota} cores -> {usable}; cpu_baseline_parallel's {workers} processes "
+                 f"already use them (the figure is the same run); --cpu-all-cores N forces "
+                 f"a pool of N")
+    if every > workers:
+        line["cpu_baseline_all_cores"] = cpu_baseline_parallel(
+            tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, every,
+            timeout=args.cpu_pool_timeout,
+            why="--cpu-all-cores: every hardware thread this process may run on",
+            recipes={f: (f, v_lo, v_hi, args.line_scale, bool(args.banded), i)
+                     for i, f in enumerate(molecules)})
+
+
+def headline(job, m):
+    """Rank 0's JSON line from the timed region: value, the contract's keys, who ran where, and
+    the roofline of the accumulate kernel -- from the same launches run alone after the region
+    (asynchronous calls take turns on two lanes, so inside it a launch is never alone), with the
+    PMC passes committed under profiles/ for traffic and issue slots.
+
+    m: what the timed region measured (elapsed = max over ranks, evals_per_step = sum over ranks,
+    this rank's kernel_ms / launches from the engine's events, per_rank records)."""
+    import torch.distributed as dist
+    args, engine, tables, handles, molecules = job.args, job.engine, job.tables, job.handles, job.molecules
+    atmos, grid_args, v_lo, v_hi, dv = job.atmos, job.grid_args, job.v_lo, job.v_hi, job.dv
+    levels_local, levels_total, n = job.levels_local, job.levels_total, job.n
+    rank, world, plan, sharded, vmr = job.rank, job.world, job.plan, job.sharded, job.vmr
+    elapsed, evals_per_step, evals_per_step_local = m.elapsed, m.evals_per_step, m.evals_per_step_local
+    kernel_ms, launches, per_rank = m.kernel_ms, m.launches, m.per_rank
+    grouped, everyone, shared = m.grouped, m.everyone, m.shared
+    ms_per_step = elapsed/args.steps*1e3
+    value = evals_per_step*args.steps/elapsed
+    accumulate_ms = kernel_ms[2]/max(launches[2], 1)
+    evals_per_launch = evals_per_step_local/max(launches[2]/args.steps, 1)
+    tflops = evals_per_launch*FLOPS_PER_EVAL/(accumulate_ms*1e-3)/1e12
+    algorithmic = evals_per_launch*BYTES_PER_EVAL/(accumulate_ms*1e-3)/1e9
+    workload = (f"BASELINE config '{args.config}': {levels_local} level(s) per GPU, "
+                f"{'+'.join(molecules)}, grid {v_lo:g}-{v_hi:g} cm-1 at {dv:g} cm-1 "
+                f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
+                + (", far-field series on" if args.farfield else "")
+                + (", banded tables" if args.banded else ""))
+    line = {
+        "metric": "line×gridpoint Voigt evals/sec (whole job; per GPU: evals_per_s_per_gpu; spectra/sec: spectra_per_s)",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": workload,
+            "lines": {t.formula: t.num_lines for t in tables},
+            "levels_total": levels_total, "atmosphere": args.profile,
+            "output": args.output,
+            "parallelism": f"(level, molecule) units over {world} GPU(s): "
+                           f"{plan.mode} sharded"
+            + (f", one grouped {args.backend} send/recv to rank 0 per step, overlapping the "
+               f"next step" if world > 1 else ""),
+        },
+        "distributed": None if not grouped else {
+            "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            "launcher": os.environ.get("PYLBL_BENCH_LAUNCHER") or (
+                "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                else "environment"),
+            "distinct_devices": len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id"),
+                                      r.get("device_index")) for r in everyone}),
+            "ranks_sharing_a_device": shared,
+            "kernels_to_exchange_ordering": "device (events between the engine's streams and "
+                                            "the exchange's, no host wait)"
+            if (args.backend == "nccl" or sharded.order_on_device) else "host (synchronize)",
+            "exchange_timeout_s": args.exchange_timeout,
+            "rccl_mapped": rccl_libraries(),
+            "bytes_to_rank0_per_step": (per_rank or [{}])[0].get("bytes_received_per_step"),
+            "exchange_alone_ms_max": max((r["unoverlapped_exchange_ms"]
+                                          for r in per_rank), default=None)
+            if per_rank else None,
+            "note": "per rank: the device it ran on, its own wall time for the timed steps, "
+                    "bytes it sent/received per step, host time it spent waiting for an "
+                    "exchange inside the timed steps (exchange_wait_ms_per_step; 0 = fully "
+                    "hidden behind the next step's kernels) and one un-overlapped step "
+                    "(kernels, then the collection alone) measured after the timed region",
+            "ranks": per_rank if per_rank else everyone,
+        },
+        "evals_per_step": evals_per_step,
+        "evals_per_s_per_gpu": value/world,
+        "spectra_per_s": levels_total*args.steps/elapsed,
+        "roofline": {
+            "bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops/FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+            "kernel": "lbl::accumulate_kernel", "avg_launch_ms": accumulate_ms,
+            "launches_timed": launches[2], "flops_per_eval": FLOPS_PER_EVAL,
+            "evals_per_launch": evals_per_launch,
+            "note": "the kernel keeps partial sums in registers and writes k once, so HBM "
+                    "carries ~8 B per grid point (traffic, from the PMC counters) and the "
+                    "binding resource is the fp64 vector ALU: achieved = SURVEY 8(d)'s 7 "
+                    "algorithmic flops per eval (5 common + 2 far-wing incl. the divide) x "
+                    "evals per launch / mean launch time (HIP events on the engine's stream); "
+                    "peak = datasheet fp64 vector rate at 2.4 GHz",
+        },
+        "roofline_hbm_algorithmic": {
+            "bound": "hbm", "achieved": algorithmic, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algorithmic/HBM_PEAK_GBS,
+            "note": "SURVEY 8(d) as written: 24 B per eval (the reference's load v[i], "
+                    "load+store k[i]) x evals / launch time.  These bytes never move here "
+                    "(register accumulation), so the 'fraction' exceeds 1 and is not a "
+                    "bandwidth; north_star's '>= 40 % of the HBM roofline' is 1.33e11 evals/s",
+        },
+        "kernel_ms_per_step": {
+            "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
+            "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
+    }
+    traffic, source = profiled_traffic(workload)
+    if traffic is not None:
+        line["roofline"]["traffic"] = traffic
+        line["roofline"]["traffic_source"] = f"profiles/{source}"
+        line["roofline"]["traffic_uncorrected"] = PROFILED_RAW.get("accumulate_kernel")
+        line["roofline"]["traffic_note"] = (
+            "traffic = WRITE_SIZE + 2 x FETCH_SIZE (the gfx950 correction for wide coalesced "
+            "reads); this kernel reads its line records through scalar loads, for which the "
+            "uncorrected count (traffic_uncorrected = WRITE_SIZE + FETCH_SIZE) may be the truer "
+            "one -- either way 0.3-0.7 TB/s, a tenth of the HBM roofline")
+    issue = profiled_issue(workload)
+    if issue is not None and issue.get("evals_per_launch"):
+        per_eval = issue["fp64_wave_instructions_per_launch"]*64./issue["evals_per_launch"]
+        # One fp64 wave-instruction occupies a SIMD's issue port for 4 cycles (16 lanes/cycle).
+        ceiling = SIMDS*BOOST_CLOCK_GHZ*1e9/4.*64./per_eval
+        issue.update({
+            "fp64_wave_instructions_per_64_evals": per_eval,
+            "issue_ceiling_evals_per_s_at_2.4GHz": ceiling,
+            "frac_of_issue_ceiling_at_2.4GHz": evals_per_launch/(accumulate_ms*1e-3)/ceiling})
+        if issue.get("gui_active_cycles_per_xcd"):
+            # Busy cycles of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs): the fraction of
+            # a SIMD's 4-cycle issue slots that fp64 instructions occupied at the clock the
+            # chip actually ran.
+            per_simd = issue["fp64_wave_instructions_per_launch"]/SIMDS*4.
+            issue["frac_of_issue_slots_at_measured_clock"] = \
+                per_simd/issue["gui_active_cycles_per_xcd"]
+        line["roofline"]["issue"] = issue
+    if not args.host_output and launches[2] > 0:
+        # Asynchronous calls that leave their spectra in HBM take turns on the engine's lanes:
+        # the tail of one accumulate grid and the head of the next overlap in time, and an
+        # event-timed launch is stretched by its neighbour.  The fraction is therefore taken
+        # from the same launches run alone (blocking calls, one lane), outside the timed
+        # region; what the events read inside it is kept beside it, and so is the fraction
+        # that follows from the step time alone (every kernel of the step in the denominator).
+        from pylbl_amd.engine import DeviceSpectra
+        engine.set_option("timing", 2)
+        engine.timing(reset=True)
+        # (3 to 10 launches per molecule: about 50 ms of them, so that the mean does not hang
+        # on one launch's clock)
+        alone_repeats = int(min(10, max(3, 50./max(ms_per_step, 1e-3))))
+        for m, levels in plan.by_molecule(rank).items():
+            scratch = DeviceSpectra(engine, len(levels), n)
+            for _ in range(alone_repeats):
+                engine.compute(handles[molecules[m]], atmos.t[levels], atmos.p[levels],
+                               vmr[molecules[m]][levels], *grid_args,
+                               remove_pedestal=args.pedestal, out=scratch)
+            scratch.free()
+        alone_ms, alone_launches = engine.timing(reset=True)
+        engine.set_option("timing", 0)
+        alone = alone_ms[2]/max(alone_launches[2], 1)
+        alone_tflops = evals_per_launch*FLOPS_PER_EVAL/(alone*1e-3)/1e12
+        line["roofline"].update({
+            "achieved": alone_tflops, "frac": alone_tflops/FP64_VECTOR_PEAK_TFLOPS,
+            "avg_launch_ms": alone, "launches_timed": alone_launches[2],
+            "avg_launch_ms_overlapped_in_step": accumulate_ms,
+            "frac_from_overlapped_launches": tflops/FP64_VECTOR_PEAK_TFLOPS,
+            "frac_from_step_time": (evals_per_step_local*FLOPS_PER_EVAL/(ms_per_step*1e-3)
+                                    / 1e12/FP64_VECTOR_PEAK_TFLOPS)})
+        line["roofline"]["note"] += (
+            "; the calls of the timed region take turns on two (with a pedestal pass: four) "
+            "engine lanes, so that the tail of one accumulate grid runs beside the next call's "
+            "prologue and the head of its grid: ms_per_step is SHORTER than the sum of the "
+            "launches run alone.  achieved / frac / avg_launch_ms come from the same launches "
+            "run alone after the timed region (blocking calls on one lane: what rocprofv3 shows "
+            "for a launch that has the chip to itself); avg_launch_ms_overlapped_in_step is "
+            "what the events read inside the region (two grids side by side), and "
+            "frac_from_step_time = 7 flops x evals_per_step / ms_per_step / peak, which needs "
+            "no launch taken alone")
+    if args.farfield:
+        # The series replaces most evaluations by one polynomial per point: "7 flops per eval x
+        # evals" is not what the kernel executes, and the quotient is not a fraction of a peak.
+        line["roofline"]["frac"] = None
+        line["roofline"]["note"] += ("; far-field series on: most of the evaluations counted in "
+                                     "`value` are not executed one by one, so `achieved` is not "
+                                     "a rate of executed flops and no fraction is given")
+    if args.host_output:
+        line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
+    if args.ablate:
+        line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
+    return line
+
+
 def run():
     args = parse()
     if args.no_extras:
@@ -1321,337 +1831,28 @@ def run():
         evals_per_step = float(evals_per_step_local)
 
     line = None
+    from types import SimpleNamespace
+    job = SimpleNamespace(args=args, engine=engine, tables=tables, handles=handles,
+                          molecules=molecules, atmos=atmos, grid_args=grid_args, v_lo=v_lo,
+                          v_hi=v_hi, dv=dv, n=n, levels_local=levels_local,
+                          levels_total=levels_total, make_tables=make_tables, rank=rank,
+                          world=world, plan=plan, sharded=sharded, vmr=vmr, workload=None)
     if rank == 0:
-        ms_per_step = elapsed/args.steps*1e3
-        value = evals_per_step*args.steps/elapsed
-        accumulate_ms = kernel_ms[2]/max(launches[2], 1)
-        evals_per_launch = evals_per_step_local/max(launches[2]/args.steps, 1)
-        tflops = evals_per_launch*FLOPS_PER_EVAL/(accumulate_ms*1e-3)/1e12
-        algorithmic = evals_per_launch*BYTES_PER_EVAL/(accumulate_ms*1e-3)/1e9
-        workload = (f"BASELINE config '{args.config}': {levels_local} level(s) per GPU, "
-                    f"{'+'.join(molecules)}, grid {v_lo:g}-{v_hi:g} cm-1 at {dv:g} cm-1 "
-                    f"({n} points), cut_off 25, remove_pedestal={args.pedestal}"
-                    + (", far-field series on" if args.farfield else "")
-                    + (", banded tables" if args.banded else ""))
-        line = {
-            "metric": "line×gridpoint Voigt evals/sec (whole job; per GPU: evals_per_s_per_gpu; spectra/sec: spectra_per_s)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": workload,
-                "lines": {t.formula: t.num_lines for t in tables},
-                "levels_total": levels_total, "atmosphere": args.profile,
-                "output": args.output,
-                "parallelism": f"(level, molecule) units over {world} GPU(s): "
-                               f"{plan.mode} sharded"
-                + (f", one grouped {args.backend} send/recv to rank 0 per step, overlapping the "
-                   f"next step" if world > 1 else ""),
-            },
-            "distributed": None if not grouped else {
-                "world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                "launcher": os.environ.get("PYLBL_BENCH_LAUNCHER") or (
-                    "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
-                    else "environment"),
-                "distinct_devices": len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id"),
-                                          r.get("device_index")) for r in everyone}),
-                "ranks_sharing_a_device": shared,
-                "kernels_to_exchange_ordering": "device (events between the engine's streams and "
-                                                "the exchange's, no host wait)"
-                if (args.backend == "nccl" or sharded.order_on_device) else "host (synchronize)",
-                "exchange_timeout_s": args.exchange_timeout,
-                "rccl_mapped": rccl_libraries(),
-                "bytes_to_rank0_per_step": (per_rank or [{}])[0].get("bytes_received_per_step"),
-                "exchange_alone_ms_max": max((r["unoverlapped_exchange_ms"]
-                                              for r in per_rank), default=None)
-                if per_rank else None,
-                "note": "per rank: the device it ran on, its own wall time for the timed steps, "
-                        "bytes it sent/received per step, host time it spent waiting for an "
-                        "exchange inside the timed steps (exchange_wait_ms_per_step; 0 = fully "
-                        "hidden behind the next step's kernels) and one un-overlapped step "
-                        "(kernels, then the collection alone) measured after the timed region",
-                "ranks": per_rank if per_rank else everyone,
-            },
-            "evals_per_step": evals_per_step,
-            "evals_per_s_per_gpu": value/world,
-            "spectra_per_s": levels_total*args.steps/elapsed,
-            "roofline": {
-                "bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tflops/FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                "kernel": "lbl::accumulate_kernel", "avg_launch_ms": accumulate_ms,
-                "launches_timed": launches[2], "flops_per_eval": FLOPS_PER_EVAL,
-                "evals_per_launch": evals_per_launch,
-                "note": "the kernel keeps partial sums in registers and writes k once, so HBM "
-                        "carries ~8 B per grid point (traffic, from the PMC counters) and the "
-                        "binding resource is the fp64 vector ALU: achieved = SURVEY 8(d)'s 7 "
-                        "algorithmic flops per eval (5 common + 2 far-wing incl. the divide) x "
-                        "evals per launch / mean launch time (HIP events on the engine's stream); "
-                        "peak = datasheet fp64 vector rate at 2.4 GHz",
-            },
-            "roofline_hbm_algorithmic": {
-                "bound": "hbm", "achieved": algorithmic, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algorithmic/HBM_PEAK_GBS,
-                "note": "SURVEY 8(d) as written: 24 B per eval (the reference's load v[i], "
-                        "load+store k[i]) x evals / launch time.  These bytes never move here "
-                        "(register accumulation), so the 'fraction' exceeds 1 and is not a "
-                        "bandwidth; north_star's '>= 40 % of the HBM roofline' is 1.33e11 evals/s",
-            },
-            "kernel_ms_per_step": {
-                "prepare": kernel_ms[0]/args.steps, "schedule": kernel_ms[1]/args.steps,
-                "accumulate": kernel_ms[2]/args.steps, "pedestal": kernel_ms[3]/args.steps},
-        }
-        traffic, source = profiled_traffic(workload)
-        if traffic is not None:
-            line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_source"] = f"profiles/{source}"
-            line["roofline"]["traffic_uncorrected"] = PROFILED_RAW.get("accumulate_kernel")
-            line["roofline"]["traffic_note"] = (
-                "traffic = WRITE_SIZE + 2 x FETCH_SIZE (the gfx950 correction for wide coalesced "
-                "reads); this kernel reads its line records through scalar loads, for which the "
-                "uncorrected count (traffic_uncorrected = WRITE_SIZE + FETCH_SIZE) may be the truer "
-                "one -- either way 0.3-0.7 TB/s, a tenth of the HBM roofline")
-        issue = profiled_issue(workload)
-        if issue is not None and issue.get("evals_per_launch"):
-            per_eval = issue["fp64_wave_instructions_per_launch"]*64./issue["evals_per_launch"]
-            # One fp64 wave-instruction occupies a SIMD's issue port for 4 cycles (16 lanes/cycle).
-            ceiling = SIMDS*BOOST_CLOCK_GHZ*1e9/4.*64./per_eval
-            issue.update({
-                "fp64_wave_instructions_per_64_evals": per_eval,
-                "issue_ceiling_evals_per_s_at_2.4GHz": ceiling,
-                "frac_of_issue_ceiling_at_2.4GHz": evals_per_launch/(accumulate_ms*1e-3)/ceiling})
-            if issue.get("gui_active_cycles_per_xcd"):
-                # Busy cycles of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs): the fraction of
-                # a SIMD's 4-cycle issue slots that fp64 instructions occupied at the clock the
-                # chip actually ran.
-                per_simd = issue["fp64_wave_instructions_per_launch"]/SIMDS*4.
-                issue["frac_of_issue_slots_at_measured_clock"] = \
-                    per_simd/issue["gui_active_cycles_per_xcd"]
-            line["roofline"]["issue"] = issue
-        if not args.host_output and launches[2] > 0:
-            # Asynchronous calls that leave their spectra in HBM take turns on the engine's lanes:
-            # the tail of one accumulate grid and the head of the next overlap in time, and an
-            # event-timed launch is stretched by its neighbour.  The fraction is therefore taken
-            # from the same launches run alone (blocking calls, one lane), outside the timed
-            # region; what the events read inside it is kept beside it, and so is the fraction
-            # that follows from the step time alone (every kernel of the step in the denominator).
-            from pylbl_amd.engine import DeviceSpectra
-            engine.set_option("timing", 2)
-            engine.timing(reset=True)
-            # (3 to 10 launches per molecule: about 50 ms of them, so that the mean does not hang
-            # on one launch's clock)
-            alone_repeats = int(min(10, max(3, 50./max(ms_per_step, 1e-3))))
-            for m, levels in plan.by_molecule(rank).items():
-                scratch = DeviceSpectra(engine, len(levels), n)
-                for _ in range(alone_repeats):
-                    engine.compute(handles[molecules[m]], atmos.t[levels], atmos.p[levels],
-                                   vmr[molecules[m]][levels], *grid_args,
-                                   remove_pedestal=args.pedestal, out=scratch)
-                scratch.free()
-            alone_ms, alone_launches = engine.timing(reset=True)
-            engine.set_option("timing", 0)
-            alone = alone_ms[2]/max(alone_launches[2], 1)
-            alone_tflops = evals_per_launch*FLOPS_PER_EVAL/(alone*1e-3)/1e12
-            line["roofline"].update({
-                "achieved": alone_tflops, "frac": alone_tflops/FP64_VECTOR_PEAK_TFLOPS,
-                "avg_launch_ms": alone, "launches_timed": alone_launches[2],
-                "avg_launch_ms_overlapped_in_step": accumulate_ms,
-                "frac_from_overlapped_launches": tflops/FP64_VECTOR_PEAK_TFLOPS,
-                "frac_from_step_time": (evals_per_step_local*FLOPS_PER_EVAL/(ms_per_step*1e-3)
-                                        / 1e12/FP64_VECTOR_PEAK_TFLOPS)})
-            line["roofline"]["note"] += (
-                "; the calls of the timed region take turns on two (with a pedestal pass: four) "
-                "engine lanes, so that the tail of one accumulate grid runs beside the next call's "
-                "prologue and the head of its grid: ms_per_step is SHORTER than the sum of the "
-                "launches run alone.  achieved / frac / avg_launch_ms come from the same launches "
-                "run alone after the timed region (blocking calls on one lane: what rocprofv3 shows "
-                "for a launch that has the chip to itself); avg_launch_ms_overlapped_in_step is "
-                "what the events read inside the region (two grids side by side), and "
-                "frac_from_step_time = 7 flops x evals_per_step / ms_per_step / peak, which needs "
-                "no launch taken alone")
-        if args.farfield:
-            # The series replaces most evaluations by one polynomial per point: "7 flops per eval x
-            # evals" is not what the kernel executes, and the quotient is not a fraction of a peak.
-            line["roofline"]["frac"] = None
-            line["roofline"]["note"] += ("; far-field series on: most of the evaluations counted in "
-                                         "`value` are not executed one by one, so `achieved` is not "
-                                         "a rate of executed flops and no fraction is given")
-        if args.host_output:
-            line["INVALID"] = "host output: PCIe copies inside the step (reported for DESIGN.md)"
-        if args.ablate:
-            line["INVALID"] = f"ablation {args.ablate}: part of the work was skipped"
+        line = headline(job, SimpleNamespace(
+            elapsed=elapsed, evals_per_step=evals_per_step,
+            evals_per_step_local=evals_per_step_local, kernel_ms=kernel_ms, launches=launches,
+            per_rank=per_rank, grouped=grouped, everyone=everyone, shared=shared))
+        job.workload = line["config"]["workload"]
 
     # ---- untimed legs, one GPU only -----------------------------------------------------------
     plain = world == 1 and not args.force_group and not args.ablate and not args.host_output
     shared_db = None
     if plain and rank == 0 and args.extras != "none":
-        handle_list = [handles[f] for f in molecules]
-        t1, p1 = atmos.t[:1], atmos.p[:1]
-        vmr1 = {f: atmos.vmr[f][:1] for f in molecules}
-        if leg("sustained"):
-            line["sustained"] = lines_leg(
-                engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
-                remove_pedestal=args.pedestal, min_seconds=2.,
-                label="the timed step repeated for >= 2 s (clocks at their sustained level)")
-        if leg("overlap") and not args.pedestal and args.config == "target":
-            # The timed step's plain calls take turns on two lanes (the next call's prologue and the
-            # head of its accumulate grid beside the tail of this one's).  The same step with the
-            # calls back to back on one stream (engine option overlap_plain = 0: every launch has
-            # the chip to itself, as the launches `roofline` divides by), for the record.
-            engine.set_option("overlap_plain", 0)
-            try:
-                line["single_lane_option"] = lines_leg(
-                    engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
-                    remove_pedestal=False, ring=2,
-                    label="the timed step with its calls back to back on one lane "
-                          "(engine option overlap_plain = 0), two sets of output blocks")
-            finally:
-                engine.set_option("overlap_plain", 1)
-        if leg("pedestal") and not args.pedestal:
-            line["pedestal_option"] = lines_leg(
-                engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
-                remove_pedestal=True, ring=2,
-                label="same workload with remove_pedestal=True (the default through "
-                      "compute_absorption, spectroscopy.py:163-164), two sets of output blocks "
-                      "used in turn like the timed step's")
-        if leg("atmosphere"):
-            standard = synthetic.standard_atmosphere(8)
-            line["standard_atmosphere_option"] = lines_leg(
-                engine, handle_list, tables, standard.t, standard.p,
-                {f: standard.vmr[f] for f in molecules}, grid_args, max(args.steps//4, 2),
-                remove_pedestal=True,
-                label="8 standard-atmosphere levels (1013 hPa ... 0.1 hPa) in one batched call "
-                      "per molecule, remove_pedestal=True")
-        if leg("banded") and not args.banded:
-            banded_tables = make_tables(True)
-            banded_handles = [engine.load(t) for t in banded_tables]
-            line["banded_table_option"] = lines_leg(
-                engine, banded_handles, banded_tables, t1, p1, vmr1, grid_args, args.steps,
-                remove_pedestal=True,
-                label="same line counts clustered in 8 Gaussian bands per molecule "
-                      "(synthetic.banded_line_table), remove_pedestal=True")
-            for h in banded_handles:
-                engine.free(h)
-        if leg("dense") and args.config == "target":
-            # A table several times denser than the workload's (dozens of pressure-shifted lines
-            # alternate between two windows at every integer wavenumber): the step with and
-            # without the pedestal, whose chain such tables used to send to its serial form.
-            dense = [synthetic.banded_line_table("CO2", v_lo, v_hi, num_lines=1_600_000, bands=8,
-                                                 seed=5, inside=True)]
-            dense_handles = [engine.load(t) for t in dense]
-            dense_vmr = {"CO2": atmos.vmr["CO2"][:1]} if "CO2" in atmos.vmr else \
-                {"CO2": np.asarray([3.6e-4])}
-            dense_plain = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
-                              max(args.steps//2, 2), remove_pedestal=False, ring=2,
-                              label="one molecule, 1.6 M lines in 8 Gaussian bands inside the grid "
-                                    "(synthetic.banded_line_table(inside=True))")
-            with_pedestal = lines_leg(engine, dense_handles, dense, t1, p1, dense_vmr, grid_args,
-                                      max(args.steps//2, 2), remove_pedestal=True, ring=2,
-                                      label="the same with remove_pedestal=True")
-            line["dense_table_option"] = {"plain": dense_plain, "remove_pedestal": with_pedestal,
-                                          "lines": int(dense[0].num_lines)}
-            for h in dense_handles:
-                engine.free(h)
+        lines_option_legs(job, line, leg)
         if leg("small") and args.config == "target":
-            small = {}
-            for name in ("0", "1"):
-                mols, lo, hi, step_cm, _ = CONFIGS[name]
-                ga = synthetic.grid_arguments(np.asarray([lo, lo + step_cm, hi - step_cm]))
-                small_tables = [synthetic.line_table(f, lo, hi) for f in mols]
-                small_handles = [engine.load(t) for t in small_tables]
-                small[f"config{name}"] = lines_leg(
-                    engine, small_handles, small_tables, t1, p1,
-                    {f: atmos.vmr[f][:1] for f in mols}, ga, 50, min_seconds=0.3, ring=4,
-                    label=f"BASELINE configs[{name}]: {'+'.join(mols)}, {lo:g}-{hi:g} cm-1 at "
-                          f"{step_cm:g} cm-1; throughput of asynchronous calls into a ring of 4 "
-                          f"output blocks")
-                if name == "0":
-                    # The three-kernel call as a replayed HIP graph (engine option graphs): the
-                    # ring of asynchronous calls again, and the blocking call that returns a host
-                    # array -- what the reference's caller sees (gas_optics.py:61-91) -- timed call
-                    # by call, with the option off and on.
-                    entry = small["config0"]
-                    x0 = atmos.vmr[mols[0]][:1]
-                    entry["graph_replay_option"] = {}
-                    for graphs in (0, 1):
-                        engine.set_option("graphs", graphs)
-                        for _ in range(50):
-                            engine.compute(small_handles[0], t1, p1, x0, *ga)
-                        times = []
-                        for _ in range(400):
-                            begin = time.perf_counter()
-                            engine.compute(small_handles[0], t1, p1, x0, *ga)
-                            times.append(time.perf_counter() - begin)
-                        ring = lines_leg(engine, small_handles, small_tables, t1, p1,
-                                         {f: atmos.vmr[f][:1] for f in mols}, ga, 50,
-                                         min_seconds=0.3, ring=4) if graphs else entry
-                        entry["graph_replay_option"]["on" if graphs else "off"] = {
-                            "ring_evals_per_s": ring["value"],
-                            "ring_us_per_call": ring["ms_per_step"]*1e3/len(small_handles),
-                            "blocking_call_us_median": float(np.median(times))*1e6,
-                            "blocking_call_us_min": min(times)*1e6}
-                    engine.set_option("graphs", 0)
-                    entry["graph_replay_option"]["shipped"] = "off (engine option graphs = 0)"
-                for h in small_handles:
-                    engine.free(h)
-            line["small_grid_options"] = small
+            small_grid_legs(job, line)
         if leg("farfield") and not args.farfield:
-            engine.set_option("farfield", 1)
-            far = {}
-            for ped in (False, True):
-                key = "remove_pedestal" if ped else "plain"
-                far[key] = lines_leg(
-                    engine, handle_list, tables, t1, p1, vmr1, grid_args, args.steps,
-                    remove_pedestal=ped)
-                # What the series leaves to be executed point by point is no longer "7 flops x the
-                # closed-form evals": the fraction is the share of the chip's fp64 ISSUE SLOTS the
-                # launch filled -- executed fp64 wave-instructions (PMC pass of this same
-                # workload, profiles/) over the launch's duration here, timed alone.
-                calls = [(h, t1, p1, vmr1[tb.formula], grid_args, {"remove_pedestal": ped})
-                         for h, tb in zip(handle_list, tables)]
-                alone = alone_roofline(engine, calls, far[key]["evals_per_step"], repeats=3)
-                far_workload = workload.replace(
-                    "remove_pedestal=False", f"remove_pedestal={ped}") + ", far-field series on"
-                roof = {"bound": "valu_fp64_issue", "unit": "fraction of fp64 issue slots",
-                        "kernel": "lbl::accumulate_kernel<8>",
-                        "avg_launch_ms": alone["avg_launch_ms"],
-                        "accumulate_ms_per_step_alone": alone["accumulate_ms_per_step_alone"],
-                        "farfield_series_ms_per_step_alone":
-                            alone["farfield_series_ms_per_step_alone"],
-                        "launches_timed": alone["launches_timed"], "frac": None, "traffic": None}
-                issue = issue_slot_fraction(profiled_issue(far_workload), alone["avg_launch_ms"])
-                if issue is not None:
-                    roof["issue"] = issue
-                    roof["frac"] = issue.get("frac_of_issue_slots_at_measured_clock",
-                                             issue["frac_of_issue_slots_at_2.4GHz"])
-                    roof["achieved"], roof["peak"] = roof["frac"], 1.0
-                for kernel in ("farfield_kernel", "farfield_group_kernel"):
-                    counted, source = profiled_traffic(far_workload, kernel)
-                    if counted is not None:
-                        roof.setdefault("series_kernels", {})[kernel] = {
-                            "hbm_bytes_per_launch": counted, "source": f"profiles/{source}"}
-                if "series_kernels" in roof and alone["farfield_series_ms_per_step_alone"] > 0.:
-                    moved = sum(v["hbm_bytes_per_launch"] for v in roof["series_kernels"].values())
-                    # (one launch of each per molecule call)
-                    seconds = alone["farfield_series_ms_per_step_alone"]*1e-3/len(handle_list)
-                    roof["series_kernels"]["hbm"] = {
-                        "bound": "hbm", "achieved": moved/seconds/1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": moved/seconds/1e9/HBM_PEAK_GBS,
-                        "note": "HBM bytes of the two series kernels (PMC) / their duration here"}
-                roof["note"] = (
-                    "far-field series on: frac = executed fp64 wave-instructions per "
-                    "accumulate_kernel<8> launch (rocprofv3 --pmc pass of this workload, "
-                    "profiles/) x 4 cycles / (1024 SIMDs x shader clock x launch duration, HIP "
-                    "events, launches run alone); None until a counter summary of this exact "
-                    "workload is committed")
-                far[key]["roofline"] = roof
-            engine.set_option("farfield", 0)
-            far["note"] = ("engine option farfield=1 (pylbl_amd/csrc/farfield.h): lines at least 4 "
-                           "tile half-widths away are summed as one power series per tile "
-                           "(truncation <= ~1.5e-11 relative); same closed-form eval count; "
-                           "parity-tested at the same 1e-6 bar; what Spectroscopy(farfield=True) "
-                           "runs -- remove_pedestal is what a user of compute_absorption() gets "
-                           "by default (spectroscopy.py:163-164); never the headline value")
-            line["farfield_option"] = far
+            farfield_legs(job, line)
         if (leg("ingest") or (not args.no_cpu_baseline)) and args.config == "target":
             # One SQLite file in the reference's schema for the ingest leg and the CPU baseline.
             import tempfile
@@ -1663,123 +1864,11 @@ def run():
         if leg("ingest") and shared_db is not None:
             line["ingest"] = ingest_leg(engine, tables, shared_db, atmos, grid_args)
             line["ingest"]["fixture_written_in_s"] = db_written_s
-        if args.config == "target" and (leg("config2") or leg("config4")):
-            # The other BASELINE configs at one GPU's size (the eight README molecules on
-            # 1-5000 cm-1 serve configs[2] and configs[4]).
-            eight = [t for t in tables if t.formula in EIGHT]
-            have = {t.formula for t in eight}
-            eight += [synthetic.line_table(f, 1., 5000., scale=args.line_scale)
-                      for f in EIGHT if f not in have]
-            eight.sort(key=lambda t: EIGHT.index(t.formula))
-            eight_handles = [handles[t.formula] if t.formula in handles else engine.load(t)
-                             for t in eight]
-            if leg("config2"):
-                surface = synthetic.surface_level()
-                vmr8 = {f: surface.vmr[f][:1] for f in EIGHT}
-                entry = lines_leg(
-                    engine, eight_handles, eight, t1, p1, vmr8, grid_args, max(args.steps//2, 3),
-                    remove_pedestal=False,
-                    label="BASELINE configs[2]: 1 level, all 8 README molecules "
-                          f"({'+'.join(EIGHT)}), 1-5000 cm-1 at 0.001 cm-1 (5 M points), "
-                          "remove_pedestal=False like the headline")
-                calls = [(h, t1, p1, vmr8[tb.formula], grid_args, {"remove_pedestal": False})
-                         for h, tb in zip(eight_handles, eight)]
-                entry["roofline"] = alone_roofline(engine, calls, entry["evals_per_step"])
-                entry["lines"] = {t.formula: int(t.num_lines) for t in eight}
-                line["config2_option"] = entry
-            if leg("config4"):
-                ga4 = synthetic.grid_arguments(np.asarray([1., 1.0005, 5000. - 0.0005]))
-                rank3 = distributed.level_shard(256, 3, 8)
-                picked = list(range(rank3.start, rank3.stop, 8))        # 96, 104, 112, 120
-                line["config4_share_option"] = share_leg(
-                    engine, "4", eight, eight_handles, picked, 256, ga4, "total",
-                    max(args.steps//6, 3),
-                    label="BASELINE configs[4] (256 levels x 8 molecules, 1-5000 cm-1 at 0.0005 "
-                          "cm-1 = 10 M points, over 8 GPUs): 4 of rank 3's 32 levels "
-                          f"(levels {picked} of the 256-level standard atmosphere) x 8 molecules, "
-                          "remove_pedestal=True, n k summed over the gases on the device "
-                          "(output 'total')")
-            for t, h in zip(eight, eight_handles):
-                if t.formula not in handles:
-                    engine.free(h)
-        if args.config == "target" and leg("config3"):
-            mols3, lo3, hi3, dv3, levels3 = CONFIGS["3"]
-            ga3 = synthetic.grid_arguments(np.asarray([lo3, lo3 + dv3, hi3 - dv3]))
-            tables3 = [synthetic.line_table(f, lo3, hi3, scale=args.line_scale) for f in mols3]
-            handles3 = [engine.load(t) for t in tables3]
-            shares = {}
-            for share_rank in (0, 7):
-                block = distributed.level_shard(levels3, share_rank, 8)
-                picked = list(range(block.start, block.stop))
-                shares[share_rank] = share_leg(
-                    engine, "3", tables3, handles3, picked, levels3, ga3, "gas",
-                    max(args.steps//6, 3),
-                    label=f"BASELINE configs[3] (64-level standard atmosphere, {'+'.join(mols3)}, "
-                          f"1-3000 cm-1 at 0.001 cm-1 = 3 M points, levels sharded over 8 GPUs): "
-                          f"rank {share_rank}'s share, levels {picked[0]}-{picked[-1]} "
-                          f"({'1013-330 hPa' if share_rank == 0 else '0.3-0.1 hPa: the slowest share, it bounds the job'}), "
-                          "remove_pedestal=True, one spectrum per gas left in HBM")
-            # The share that bounds the 8-GPU job is the record's entry; rank 0's rides along.
-            line["config3_share_option"] = dict(shares[7], rank0_share=shares[0])
-            for h in handles3:
-                engine.free(h)
-        if leg("api"):
-            # What the call queues on the device: Spectroscopy sums distant lines through the
-            # far-field series by default and removes the pedestal (continua on).
-            device = line.get("farfield_option", {}).get("remove_pedestal") or \
-                line.get("pedestal_option", line)
-            line["api_call"] = api_leg(engine, tables, atmos, v_lo, v_hi, dv,
-                                       device["ms_per_step"])
-        if leg("continuum"):
-            mine = slice(0, levels_local)
-            extra = continuum_leg(engine, molecules, atmos, mine, v_lo, v_hi, dv, args.steps,
-                                  not args.no_cpu_baseline)
-            if extra is not None:
-                line["continuum_slot"] = extra
-                traffic, source = profiled_traffic(workload, "group_interp_kernel")
-                if traffic is not None:
-                    extra["roofline"]["traffic"] = traffic
-                    extra["roofline"]["traffic_source"] = f"profiles/{source}"
-            extra = cross_section_leg(engine, atmos, mine, v_lo, v_hi, dv, args.steps,
-                                      not args.no_cpu_baseline)
-            line["cross_section_slot"] = extra
-            traffic, source = profiled_traffic(workload, "xsec_interp_kernel")
-            if traffic is not None:
-                extra["roofline"]["traffic"] = traffic
-                extra["roofline"]["traffic_source"] = f"profiles/{source}"
+        other_config_legs(job, line, leg)
+        api_and_slot_legs(job, line, leg)
     if rank == 0:
         if plain and not args.no_cpu_baseline and args.extras != "none":
-            db = shared_db
-            line["cpu_baseline"] = cpu_baseline(tables, atmos, grid_v0, grid_vn, n_per_v,
-                                                args.cpu_sample_cm, args.pedestal, db=db)
-            workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
-            if workers > 1:
-                line["cpu_baseline_parallel"] = cpu_baseline_parallel(
-                    tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, workers)
-            # "All host cores" = what this process may use: the affinity mask, cut down to the
-            # cgroup's CPU quota where there is one (this pool shows a one-GPU job all 256 hardware
-            # threads of the host and allots it 16 cores' worth of time: 256 processes then share
-            # those, 8.3e9 evals/s against 1.7e10 for 16 -- profiles/bench_r05b.json).
-            usable = len(os.sched_getaffinity(0))
-            quota = cpu_quota()
-            if quota is not None:
-                usable = max(1, min(usable, int(round(quota))))
-            every = usable if args.cpu_all_cores < 0 else args.cpu_all_cores
-            if 0 < every <= workers and "cpu_baseline_parallel" in line:
-                line["cpu_baseline_all_cores"] = dict(
-                    line["cpu_baseline_parallel"],
-                    note=f"every core this process may use: affinity mask "
-                         f"{len(os.sched_getaffinity(0))} hardware threads, cgroup CPU quota "
-                         f"{quota} cores -> {usable}; cpu_baseline_parallel's {workers} processes "
-                         f"already use them (the figure is the same run); --cpu-all-cores N forces "
-                         f"a pool of N")
-            if every > workers:
-                line["cpu_baseline_all_cores"] = cpu_baseline_parallel(
-                    tables, atmos, grid_v0, grid_vn, n_per_v, args.cpu_sample_cm, every,
-                    timeout=args.cpu_pool_timeout,
-                    why="--cpu-all-cores: every hardware thread this process may run on",
-                    recipes={f: (f, v_lo, v_hi, args.line_scale, bool(args.banded), i)
-                             for i, f in enumerate(molecules)})
+            cpu_legs(job, line, shared_db)
         line["environment"] = {
             "variables": {k: v for k, v in sorted(os.environ.items())
                           if k.startswith("PYLBL_AMD_") or k in ("LBL_DEVICE", "LBL_COMPAT_CACHE",
