@@ -172,7 +172,8 @@ struct Lane
         bool streamed = false, order_writers = false, add_into = false;
         char * host = nullptr;
         long long host_pitch = 0, columns = 0, base = 0;
-        double * k = nullptr;
+        double * k = nullptr;          // the block, for its write record: set by the call's last pass only
+        const double * block = nullptr; // the block, for ordering behind its earlier writers: every pass
         long long out_bytes = 0;
         hipStream_t finish_stream = nullptr;
     } finish;
@@ -570,7 +571,9 @@ struct lbl_engine
         lane.used = true;
         if (f.order_writers)
         {
-            order_after_writers(f.finish_stream, f.k, f.out_bytes, &lane);
+            // (every pass of a call in several passes: the FIRST pass's kernels are the ones that
+            // must not add into rows another lane's earlier call is still adding into)
+            order_after_writers(f.finish_stream, f.block, f.out_bytes, &lane);
         }
         for (int piece = 0; piece < f.pieces; ++piece)
         {

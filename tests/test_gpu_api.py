@@ -220,6 +220,37 @@ def test_level_chunking_and_strides(remove_pedestal):
     e.close()
 
 
+def test_gases_added_into_one_block_in_several_passes():
+    """Four gases add n k into one block, queued back to back, each call cut into several passes
+    over the levels by a tiny workspace budget: every pass -- not only the last -- has to wait for
+    the earlier gases' kernels that add into the same rows (they run on other lanes)."""
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    atmos = synthetic.standard_atmosphere(12)
+    v0, vn, npv = 1250, 1330, 500
+    n = (vn - v0)*npv
+    formulas = ["CH4", "H2O", "CO2", "N2O"]
+    tables = [synthetic.line_table(f, 1200., 1400., num_lines=20000 + 5000*i, seed=90 + i,
+                                   tips_range=(150, 400)) for i, f in enumerate(formulas)]
+    handles = [e.load(t) for t in tables]
+    apart = [e.compute(h, atmos.t, atmos.p, atmos.vmr[f], v0, vn, npv, remove_pedestal=True,
+                       scale_density=True).copy() for h, f in zip(handles, formulas)]
+    expected = np.zeros_like(apart[0])
+    for part in apart:
+        expected += part                        # the order the block receives them in
+    e.set_option("workspace_bytes", 1 << 20)    # a few levels per pass
+    total = DeviceSpectra(e, 12, n)
+    for repeat in range(5):
+        e.fill_zero(total, asynchronous=True)
+        for h, f in zip(handles, formulas):
+            e.compute(h, atmos.t, atmos.p, atmos.vmr[f], v0, vn, npv, remove_pedestal=True,
+                      scale_density=True, accumulate=True, out=total, asynchronous=True)
+        e.synchronize()
+        assert np.array_equal(total.to_host(), expected), f"repeat {repeat}"
+    total.free()
+    e.close()
+
+
 def test_error_paths():
     from pylbl_amd.engine import Engine
     from pylbl_amd.errors import EngineError
