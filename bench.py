@@ -1609,6 +1609,8 @@ def run():
     result_stream = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    # (dmabuf IPC is what RCCL needs on this pool; the launchers export it, a bare environment may not)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
