@@ -1420,7 +1420,7 @@ def headline(job, m):
     levels_local, levels_total, n = job.levels_local, job.levels_total, job.n
     rank, world, plan, sharded, vmr = job.rank, job.world, job.plan, job.sharded, job.vmr
     elapsed, evals_per_step, evals_per_step_local = m.elapsed, m.evals_per_step, m.evals_per_step_local
-    kernel_ms, launches, per_rank = m.kernel_ms, m.launches, m.per_rank
+    kernel_ms, launches, per_rank, busy_ms = m.kernel_ms, m.launches, m.per_rank, m.busy_ms
     grouped, everyone, shared = m.grouped, m.everyone, m.shared
     ms_per_step = elapsed/args.steps*1e3
     value = evals_per_step*args.steps/elapsed
@@ -1557,7 +1557,14 @@ def headline(job, m):
             "avg_launch_ms_overlapped_in_step": accumulate_ms,
             "frac_from_overlapped_launches": tflops/FP64_VECTOR_PEAK_TFLOPS,
             "frac_from_step_time": (evals_per_step_local*FLOPS_PER_EVAL/(ms_per_step*1e-3)
-                                    / 1e12/FP64_VECTOR_PEAK_TFLOPS)})
+                                    / 1e12/FP64_VECTOR_PEAK_TFLOPS),
+            # HIP events over the timed region itself: the time during which at least one
+            # accumulate launch was running (the union of the launches' intervals on the device's
+            # clock, lbl_timing_busy), and the kernel's rate over exactly that time.
+            "accumulate_busy_ms_per_step_in_region": busy_ms[2]/args.steps,
+            "frac_while_running_in_region": (evals_per_step_local*FLOPS_PER_EVAL*args.steps
+                                             / max(busy_ms[2]*1e-3, 1e-12)/1e12
+                                             / FP64_VECTOR_PEAK_TFLOPS)})
         line["roofline"]["note"] += (
             "; the calls of the timed region take turns on two (with a pedestal pass: four) "
             "engine lanes, so that the tail of one accumulate grid runs beside the next call's "
@@ -1567,7 +1574,10 @@ def headline(job, m):
             "for a launch that has the chip to itself); avg_launch_ms_overlapped_in_step is "
             "what the events read inside the region (two grids side by side), and "
             "frac_from_step_time = 7 flops x evals_per_step / ms_per_step / peak, which needs "
-            "no launch taken alone")
+            "no launch taken alone; frac_while_running_in_region = 7 flops x the region's evals / "
+            "the time at least one accumulate launch was running inside the timed region (union "
+            "of the launches' event intervals) / peak: the kernel's rate measured over the timed "
+            "region itself, overlap counted once")
     if args.farfield:
         # The series replaces most evaluations by one polynomial per point: "7 flops per eval x
         # evals" is not what the kernel executes, and the quotient is not a fraction of a peak.
@@ -1789,6 +1799,7 @@ def run():
         step()
     fence()
     elapsed = time.perf_counter() - start
+    busy_ms = engine.timing_busy()
     kernel_ms, launches = engine.timing(reset=True)
     engine.set_option("timing", 0)
 
@@ -1843,6 +1854,7 @@ def run():
         line = headline(job, SimpleNamespace(
             elapsed=elapsed, evals_per_step=evals_per_step,
             evals_per_step_local=evals_per_step_local, kernel_ms=kernel_ms, launches=launches,
+            busy_ms=busy_ms,
             per_rank=per_rank, grouped=grouped, everyone=everyone, shared=shared))
         job.workload = line["config"]["workload"]
 

@@ -200,6 +200,13 @@ int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
  * interpolation.  Synchronizes the streams. */
 int lbl_timing(lbl_engine *engine, double ms[8], int64_t launches[8], int32_t reset);
 
+/* Same indices: the milliseconds during which AT LEAST ONE timed launch of the kind was running
+ * since the last reset (the union of the launches' intervals on the device's clock).  Queued calls
+ * take turns on several streams and their launches overlap: the sum lbl_timing returns then counts
+ * such a stretch twice, this counts it once -- evals / busy time is the rate of the kernel while any
+ * of it runs.  Call it BEFORE the lbl_timing(..., reset = 1) that clears both. */
+int lbl_timing_busy(lbl_engine *engine, double busy_ms[8]);
+
 /* The engine's first HIP stream (a hipStream_t), for callers that time with their own events.
  * Blocking calls run on it back to back; asynchronous calls into device memory rotate over
  * several streams, so events on this one do not bracket them (use lbl_synchronize / lbl_timing,

@@ -469,8 +469,27 @@ int lbl_timing(lbl_engine * engine, double ms[8], int64_t launches[8], int32_t r
         {
             engine->time_ms[i] = 0.;
             engine->launches[i] = 0;
+            engine->busy_ms[i] = 0.;
         }
     }
+    return LBL_OK;
+}
+
+int lbl_timing_busy(lbl_engine * engine, double busy_ms[8])
+{
+    if (engine == nullptr || busy_ms == nullptr) return LBL_BAD_ARGUMENT;
+    EngineLock lock(engine->mutex);
+    try
+    {
+        HIP_TRY(hipSetDevice(engine->device));
+        engine->drain_lanes();
+        engine->drain_spans();
+    }
+    catch (const HipFailure & f)
+    {
+        return fail(engine, LBL_ERROR, f.message);
+    }
+    for (int i = 0; i < kTimeKinds; ++i) busy_ms[i] = engine->busy_ms[i];
     return LBL_OK;
 }
 

@@ -444,6 +444,7 @@ struct lbl_engine
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     double time_ms[kTimeKinds] = {};
+    double busy_ms[kTimeKinds] = {};    // time during which AT LEAST ONE timed span of the kind ran
     long long launches[kTimeKinds] = {};
 
     hipEvent_t take_event()
@@ -475,15 +476,47 @@ struct lbl_engine
         if (spans.size() >= 4096) drain_spans();
     }
 
+    // Sums the spans' durations per kind (time_ms) and, because calls on different lanes run side
+    // by side, also the length of the UNION of the spans of a kind on the device's clock (busy_ms:
+    // two launches that overlap count once) -- positions taken against the batch's first event.
     void drain_spans()
     {
+        if (spans.empty()) return;
+        std::vector<std::pair<float, float>> placed[kTimeKinds];
+        for (auto & s : spans) HIP_TRY(hipEventSynchronize(s.end));
+        const hipEvent_t origin = spans.front().begin;
         for (auto & s : spans)
         {
-            HIP_TRY(hipEventSynchronize(s.end));
-            float ms = 0.f;
+            float ms = 0.f, from = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s.begin, s.end));
             time_ms[s.kind] += ms;
             launches[s.kind] += s.counts;
+            if (s.begin != origin) HIP_TRY(hipEventElapsedTime(&from, origin, s.begin));
+            placed[s.kind].push_back({from, from + ms});
+        }
+        for (int kind = 0; kind < kTimeKinds; ++kind)
+        {
+            auto & list = placed[kind];
+            std::sort(list.begin(), list.end());
+            float reach = 0.f;
+            bool open = false;
+            for (const auto & interval : list)
+            {
+                if (!open || interval.first > reach)
+                {
+                    busy_ms[kind] += interval.second - interval.first;
+                    reach = interval.second;
+                    open = true;
+                }
+                else if (interval.second > reach)
+                {
+                    busy_ms[kind] += interval.second - reach;
+                    reach = interval.second;
+                }
+            }
+        }
+        for (auto & s : spans)
+        {
             event_pool.push_back(s.begin);
             event_pool.push_back(s.end);
         }

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "lbl_engine_create", "lbl_engine_destroy", "lbl_last_error", "lbl_molecule_load",
     "lbl_molecule_free", "lbl_compute", "lbl_compute_streamed", "lbl_finish_deferred",
     "lbl_deferred", "lbl_cancel_deferred", "lbl_synchronize", "lbl_set_option", "lbl_timing",
+    "lbl_timing_busy",
     "lbl_stream", "lbl_order_stream_after_engine", "lbl_order_engine_after_stream",
     "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
@@ -115,6 +116,7 @@ def library():
     lib.lbl_synchronize.argtypes = [c_void_p]
     lib.lbl_set_option.argtypes = [c_void_p, c_char_p, c_int64]
     lib.lbl_timing.argtypes = [c_void_p, f64p, i64p, c_int32]
+    lib.lbl_timing_busy.argtypes = [c_void_p, f64p]
     lib.lbl_stream.argtypes = [c_void_p]
     lib.lbl_stream.restype = c_void_p
     lib.lbl_order_stream_after_engine.argtypes = [c_void_p, c_void_p]
@@ -647,6 +649,14 @@ class Engine(object):
         launches = (c_int64*8)()
         self._check(self.lib.lbl_timing(self.handle, ms, launches, 1 if reset else 0))
         return list(ms), list(launches)
+
+    def timing_busy(self):
+        """milliseconds[8] (indices as timing()) during which at least one timed launch of the kind
+        was running since the last reset: launches of calls on different lanes overlap, and what
+        timing() sums twice this counts once.  Read it before timing(reset=True)."""
+        ms = (c_double*8)()
+        self._check(self.lib.lbl_timing_busy(self.handle, ms))
+        return list(ms)
 
     @property
     def stream(self):

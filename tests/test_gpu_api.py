@@ -251,6 +251,49 @@ def test_gases_added_into_one_block_in_several_passes():
     e.close()
 
 
+def test_busy_time_counts_overlapping_launches_once():
+    """lbl_timing sums launch durations; lbl_timing_busy gives the time at least one launch of the
+    kind ran.  Blocking calls: the same.  Queued calls on two lanes: the launches overlap, the sum
+    exceeds the busy time, and the busy time cannot exceed the wall time of the batch."""
+    import time
+    from pylbl_amd.engine import DeviceSpectra, Engine
+    e = Engine(0)
+    table = synthetic.line_table("CO2", 1., 3000., num_lines=200_000, seed=5)
+    h = e.load(table)
+    level = synthetic.surface_level(["CO2"])
+    v0, vn, npv = 1, 3001, 1000
+    blocks = [DeviceSpectra(e, 1, (vn - v0)*npv) for _ in range(2)]
+    args = (h, level.t, level.p, level.vmr["CO2"], v0, vn, npv)
+    for block in blocks:
+        e.compute(*args, out=block)                     # plans and workspaces of lane 0
+    for i in range(4):
+        e.compute(*args, out=blocks[i % 2], asynchronous=True)   # ... and of the second lane
+    e.synchronize()
+    e.set_option("timing", 2)
+    e.timing(reset=True)
+    for i in range(4):
+        e.compute(*args, out=blocks[i % 2])
+    busy = e.timing_busy()[2]
+    summed, launches = e.timing(reset=True)
+    assert launches[2] == 4
+    assert busy == pytest.approx(summed[2], rel=1e-3)
+    begin = time.perf_counter()
+    for i in range(8):
+        e.compute(*args, out=blocks[i % 2], asynchronous=True)
+    e.synchronize()
+    wall_ms = (time.perf_counter() - begin)*1e3
+    busy = e.timing_busy()[2]
+    summed, launches = e.timing(reset=True)
+    assert launches[2] == 8
+    assert busy < 0.95*summed[2]            # launches of successive calls run side by side
+    assert busy <= wall_ms
+    assert e.timing_busy()[2] == 0.         # cleared with the sums
+    e.set_option("timing", 0)
+    for block in blocks:
+        block.free()
+    e.close()
+
+
 def test_error_paths():
     from pylbl_amd.engine import Engine
     from pylbl_amd.errors import EngineError
