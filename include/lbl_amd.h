@@ -185,9 +185,10 @@ int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
  * small_grid_options.config0.graph_replay_option), "chain_first" (0/1: a far-field call queues its
  * pedestal chain in front of its accumulate launches; measured +-0, default 0), "interp_shape"
  * (experiments: shape of the continuum interpolation kernels, 10 PT + LV for one continuum,
- * 100 + 10 PT + LV for groups; 0 = by the number of levels), "item_order" (0/1: work items heaviest
- * first by exact weight / by quarter-octave weight class with grid order inside a class, default 1:
- * neighbouring tiles then run together and share line records in L2), "item_floor" (experiments:
+ * 100 + 10 PT + LV for groups; 0 = by the number of levels), "item_order" (0/1/2: work items heaviest
+ * first by exact weight / by quarter-octave weight class with grid order inside a class, so that
+ * neighbouring tiles run together and share line records in L2 / the same with every XCD given two
+ * contiguous stretches of a class's items, so that a region's records go into one L2; default 2), "item_floor" (experiments:
  * fewest lines per work item), "ablate" (timing diagnostics only: results are wrong; refused from
  * $PYLBL_AMD_OPTIONS). */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);

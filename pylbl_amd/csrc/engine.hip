@@ -396,7 +396,7 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->chain_first = (int)value;
     }
-    else if (key == "item_order" && (value == 0 || value == 1))
+    else if (key == "item_order" && value >= 0 && value <= 2)
     {
         engine->item_order = (int)value;
     }

@@ -430,7 +430,7 @@ struct lbl_engine
     int scan_chain = 1;             // pedestal chain by relaxation (pedestal.h), serial chain behind it
     int relax_launches = 0;         // relaxation launches before the serial chain (2 ... 7; 0: by the table)
     int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
-    int item_order = 1;             // 0: items by exact weight; 1: by weight class, grid order within
+    int item_order = 2;             // 0 exact weight, 1 weight classes in grid order, 2 ... dealt to the XCDs in paired stretches
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
     int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size count as small

@@ -198,14 +198,15 @@ def test_item_order_changes_no_bit(engine, farfield):
     molecule = engine.load(table)
     engine.set_option("farfield", farfield)
     results = []
-    for order in (0, 1):
+    for order in (0, 1, 2):
         engine.set_option("item_order", order)
         results.append(engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"],
                                       400, 900, 200, remove_pedestal=True).copy())
     engine.set_option("farfield", 0)
     engine.free(molecule)
     assert np.isfinite(results[0]).all() and results[0].max() > 0.
-    assert np.array_equal(results[0], results[1])
+    engine.set_option("item_order", 2)
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
 
 
 def test_unsorted_rows_and_skip_policy(engine, oracle):
