@@ -1,0 +1,9 @@
+# The default workload (1 level, H2O + CO2, 5 M points), direct kernel: the accumulate launch run
+# alone with parts switched off (1 general ranges, 2 fast ranges, 4 clipping lines, 16 core lines,
+# 32 inner points).
+for ablate in 0 1 2 3 4 16 32 0; do
+  python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --ablate $ablate 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('ablate %-3s ms/step %.3f accumulate launch alone %.4f ms' % ('$ablate', d['ms_per_step'], d['roofline']['avg_launch_ms']))"
+done
