@@ -16,13 +16,16 @@ for path in sorted(glob.glob(f"{src}/pass*/*/*_counter_collection.csv")):
         name = row["Kernel_Name"].split("(")[0]
         values[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 line = json.loads(open(f"{src}/bench1.json").read().strip().splitlines()[-1])
-launches_per_step = line["roofline"]["launches_timed"]/line["steps"]
+# Evaluations per accumulate launch: what the profiled run itself reports (roofline.evals_per_launch
+# = this rank's evals per step / accumulate launches per step INSIDE the timed region; never
+# roofline.launches_timed, which counts the launches re-run alone after the region).
+evals_per_launch = line["roofline"]["evals_per_launch"]
 summary = {
     "tag": tag,
     "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline --extras $EXTRAS (one pass per group, scripts/profile_counters.sh)",
     "workload": line["config"]["workload"],
-    "evals_per_accumulate_launch": line["evals_per_step"]/launches_per_step,
+    "evals_per_accumulate_launch": evals_per_launch,
     "kernels": {},
 }
 for name, counters in values.items():
