@@ -95,7 +95,7 @@ def compact(line, full_record=None):
     out["config"] = pick(config, ("workload", "lines", "levels_total", "atmosphere", "output"))
     out["config"]["parallelism"] = config.get("parallelism", "").split(":")[-1].strip()[:80]
     out.update(pick(line, ("evals_per_step", "evals_per_s_per_gpu", "spectra_per_s", "INVALID",
-                           "non_default_engine_options")))
+                           "non_default_engine_options", "kernel_ms_per_step")))
     roofline = pick(line["roofline"], ROOFLINE)
     if isinstance(line["roofline"].get("issue"), dict):
         roofline["issue"] = pick(line["roofline"]["issue"], ISSUE)

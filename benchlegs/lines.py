@@ -231,8 +231,7 @@ def lines_option_legs(job, line, leg):
 
 
 def small_grid_legs(job, line):
-    """BASELINE configs[0] and [1] as rings of asynchronous calls, and configs[0] as a replayed
-    HIP graph against plain launches."""
+    """BASELINE configs[0] and [1] as rings of asynchronous calls."""
     engine, atmos = job.engine, job.atmos
     handle_list, t1, p1, vmr1 = first_level(job)
     from pylbl_amd import synthetic
@@ -248,33 +247,8 @@ def small_grid_legs(job, line):
             label=f"BASELINE configs[{name}]: {'+'.join(mols)}, {lo:g}-{hi:g} cm-1 at "
                   f"{step_cm:g} cm-1; throughput of asynchronous calls into a ring of 4 "
                   f"output blocks")
-        if name == "0":
-            # The three-kernel call as a replayed HIP graph (engine option graphs): the
-            # ring of asynchronous calls again, and the blocking call that returns a host
-            # array -- what the reference's caller sees (gas_optics.py:61-91) -- timed call
-            # by call, with the option off and on.
-            entry = small["config0"]
-            x0 = atmos.vmr[mols[0]][:1]
-            entry["graph_replay_option"] = {}
-            for graphs in (0, 1):
-                engine.set_option("graphs", graphs)
-                for _ in range(50):
-                    engine.compute(small_handles[0], t1, p1, x0, *ga)
-                times = []
-                for _ in range(400):
-                    begin = time.perf_counter()
-                    engine.compute(small_handles[0], t1, p1, x0, *ga)
-                    times.append(time.perf_counter() - begin)
-                ring = lines_leg(engine, small_handles, small_tables, t1, p1,
-                                 {f: atmos.vmr[f][:1] for f in mols}, ga, 50,
-                                 min_seconds=0.3, ring=4) if graphs else entry
-                entry["graph_replay_option"]["on" if graphs else "off"] = {
-                    "ring_evals_per_s": ring["value"],
-                    "ring_us_per_call": ring["ms_per_step"]*1e3/len(small_handles),
-                    "blocking_call_us_median": float(np.median(times))*1e6,
-                    "blocking_call_us_min": min(times)*1e6}
-            engine.set_option("graphs", 0)
-            entry["graph_replay_option"]["shipped"] = "off (engine option graphs = 0)"
+        small[f"config{name}"]["us_per_call"] = \
+            small[f"config{name}"]["ms_per_step"]*1e3/len(small_handles)
         for h in small_handles:
             engine.free(h)
     line["small_grid_options"] = small

@@ -165,32 +165,28 @@ int lbl_synchronize(lbl_engine *engine);
 int lbl_fill_zero(lbl_engine *engine, double *k, int32_t n_levels, int64_t n,
                   int64_t level_stride, int32_t flags);
 
-/* Options: "prep" (LBL_PREP_*), "points_per_lane" (0 = automatic, 1/2/4/8), "timing" (0/1/2:
- * record HIP events around every kernel; 2 = only around the accumulate and far-field series
- * launches, so that the others keep running back to back), "workspace_bytes", "overlap_pedestal" (0/1: pedestal
- * pre-pass on a side stream, default 1), "scan_chain" (0/1: the pedestal recurrence by
- * relaxation where it applies, the serial chain behind it; default 1), "relax_launches" (0, 2..7:
- * relaxation launches before the serial chain takes what has not settled; 0 = three, or five for
- * tables with more than two runs per window; default 0),
- * "skip_delivery_lanes" (0/1:
- * lbl_compute_streamed avoids the internal streams that share a hardware queue with the copy
- * stream; default 1), "farfield" (0/1: distant lines by power series, default
- * 0), "aligned_tiles" (0/1: cell-aligned tiles also without the far-field series), "lanes" (0, 2..8:
- * streams that asynchronous calls rotate over; 0 = chosen by kind of call), "overlap_plain" (0/1:
- * plain asynchronous calls on grids larger than small_points take turns on two lanes like the
- * others, so that one call's last workgroups run beside the next call's first; default 1; 0: back
- * to back on the first stream), "small_points" (grids of
- * up to so many points x levels count as short calls), "graphs" (0/1: short calls replay a HIP
- * graph of their kernels; default 0: it costs the host more than the launches, bench.py's
- * small_grid_options.config0.graph_replay_option), "chain_first" (0/1: a far-field call queues its
- * pedestal chain in front of its accumulate launches; measured +-0, default 0), "interp_shape"
- * (experiments: shape of the continuum interpolation kernels, 10 PT + LV for one continuum,
- * 100 + 10 PT + LV for groups; 0 = by the number of levels), "item_order" (0/1/2: work items heaviest
- * first by exact weight / by quarter-octave weight class with grid order inside a class, so that
- * neighbouring tiles run together and share line records in L2 / the same with every XCD given two
- * contiguous stretches of a class's items, so that a region's records go into one L2; default 2), "item_floor" (experiments:
- * fewest lines per work item), "ablate" (timing diagnostics only: results are wrong; refused from
- * $PYLBL_AMD_OPTIONS). */
+/* Options (thirteen; anything else is LBL_BAD_ARGUMENT):
+ *   "prep"                LBL_PREP_DEVICE (default) / LBL_PREP_HOST: where the per-line scalars are formed
+ *   "points_per_lane"     0 = by the grid (default), 1/2/4/8 grid points per lane of the accumulate kernel
+ *   "timing"              0/1/2: HIP events around every kernel; 2 = only around the accumulate and
+ *                         far-field series launches, so that the others keep running back to back
+ *   "workspace_bytes"     per-lane workspace that bounds the levels of one pass (default 4 GiB)
+ *   "farfield"            0/1: distant lines by their power series (farfield.h); default 0
+ *   "aligned_tiles"       0/1: cell-aligned tiles also without the far-field series; default 0
+ *   "overlap_pedestal"    0/1: pedestal pre-pass on a side stream beside the accumulate launch; default 1
+ *   "scan_chain"          0/1: the pedestal recurrence by relaxation where it applies, the serial
+ *                         chain behind it; 0 = the serial chain alone; default 1
+ *   "relax_launches"      0, 2..7: relaxation sweeps before the serial chain takes what has not
+ *                         settled; 0 = three, or five for tables with more than two runs per window
+ *   "lanes"               0, 2..8: streams that asynchronous calls rotate over; 0 = by kind of call
+ *   "overlap_plain"       0/1: plain asynchronous calls on grids larger than small_points take turns
+ *                         on two lanes, so that one call's last workgroups run beside the next
+ *                         call's first; default 1; 0 = back to back on the first stream
+ *   "small_points"        grids of up to so many points x levels count as short calls (default 2^20)
+ *   "skip_delivery_lanes" 0/1: lbl_compute_streamed avoids the internal streams that share a
+ *                         hardware queue with the copy stream; default 1
+ * A library built with -DLBL_ABLATE (scripts/ablate_*.sh; never the shipped one) also takes "ablate":
+ * parts of the accumulate kernel switched off for timing, results wrong. */
 int lbl_set_option(lbl_engine *engine, const char *name, int64_t value);
 
 /* With option timing=1 (or 2): accumulated kernel milliseconds and launch counts since the last

@@ -39,5 +39,37 @@ def build(force=False, verbose=False):
     return LIBRARY
 
 
+VARIANTS = {
+    # name: (extra flags, what it is for) -- built beside the shipped library, loaded only when
+    # $PYLBL_AMD_LIBRARY names them (engine.library()).
+    "ablate": (["-DLBL_ABLATE"], "engine option 'ablate' (scripts/ablate_*.sh): parts of the "
+                                 "accumulate kernel switched off for timing, results wrong"),
+    "asan": (["-O1", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"],
+             "host code under AddressSanitizer (scripts/checks/host_asan.sh)"),
+    "tsan": (["-O1", "-g", "-Xarch_host", "-fsanitize=thread", "-shared-libsan"],
+             "host code under ThreadSanitizer (scripts/checks/host_tsan.sh)"),
+    "ubsan": (["-O1", "-g", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host",
+               "-fno-sanitize=vptr,function", "-shared-libsan"],
+              "host code under UndefinedBehaviorSanitizer (scripts/checks/host_ubsan.sh)"),
+}
+
+
+def build_variant(name, verbose=False):
+    """pylbl_amd/liblbl_amd_<name>.so: the same translation unit with the variant's flags."""
+    extra, _ = VARIANTS[name]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    target = PACKAGE / f"liblbl_amd_{name}.so"
+    command = [hipcc] + FLAGS + extra + [str(SOURCE), "-o", str(target), "-ldl"]
+    if verbose:
+        print(" ".join(command))
+    subprocess.run(command, check=True)
+    return target
+
+
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    if len(sys.argv) > 1:
+        for variant in sys.argv[1:]:
+            build_variant(variant, verbose=True)
+    else:
+        build(force=True, verbose=True)

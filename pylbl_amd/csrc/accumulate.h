@@ -131,9 +131,20 @@ struct AccumulateArgs
     int scale_density;
     int accumulate;
     int inner_everywhere;           // 0: only the core-range lines can have inner points in a tile
-    int ablate;                     // diagnostics only: 1 skips the general ranges, 2 the fast ranges,
-                                    // ..., 64 sends the clipped windows line by line (accumulate_tile)
+#ifdef LBL_ABLATE
+    int ablate;                     // diagnostics build only (-DLBL_ABLATE, scripts/ablate_*.sh): 1 skips
+                                    // the general ranges, 2 the fast ranges, ..., 64 sends the
+                                    // clipped windows line by line (accumulate_tile)
+#endif
 };
+
+// Parts of the kernel switched off for timing diagnostics (results are then wrong): only in a
+// library built with -DLBL_ABLATE; the shipped one has no such switch anywhere.
+#ifdef LBL_ABLATE
+#define LBL_ABLATED(a, bits) (((a).ablate & (bits)) != 0)
+#else
+#define LBL_ABLATED(a, bits) false
+#endif
 
 }  // namespace lbl
 
@@ -204,7 +215,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     int fa0, fa1, fb0, fb1, e;
     // (The clipped windows are handed out eight lines at a time where clipped_ranges() sums them
     // in groups of eight.)
-    const bool clipped_in_groups = !a.inner_everywhere && !(a.ablate & 64);
+    const bool clipped_in_groups = !a.inner_everywhere && !LBL_ABLATED(a, 64);
     const float inverse = 1.f/(float)pieces;
     share_of(sc.lo, sc.a1, piece, pieces, inverse, clipped_in_groups ? 3 : 0, g.begin[0], e);
     g.count[0] = e - g.begin[0];
@@ -220,15 +231,15 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
     g.count[3] = (fa1 - fa0) & 3;
     g.begin[4] = fb0 + ((fb1 - fb0) & ~3);
     g.count[4] = (fb1 - fb0) & 3;
-    if (a.ablate & 4) { g.count[0] = 0; g.count[2] = 0; }     // diagnostics: no clipping lines
-    if (a.ablate & 8) { g.count[3] = 0; g.count[4] = 0; }     // ... no left-overs of the fast ranges
-    if (a.ablate & 16) { g.count[1] = 0; }                    // ... no core lines
-    if (!(a.ablate & 2))
+    if (LBL_ABLATED(a, 4)) { g.count[0] = 0; g.count[2] = 0; }    // diagnostics: no clipping lines
+    if (LBL_ABLATED(a, 8)) { g.count[3] = 0; g.count[4] = 0; }    // ... no left-overs of the fast ranges
+    if (LBL_ABLATED(a, 16)) { g.count[1] = 0; }                   // ... no core lines
+    if (!LBL_ABLATED(a, 2))
     {
         fast_ranges<P>(wing, fa0, fa1, fb0, fb1, v, acc);
     }
     bool slab_in_use = false;
-    if (!(a.ablate & 1))
+    if (!LBL_ABLATED(a, 1))
     {
         GeneralList walk = g;
         if (clipped_in_groups)
@@ -240,7 +251,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateArgs & a)
         general_ranges<P>(wing, core, walk, i0, i1, lane, v, acc);
         // (32: diagnostics, leaves the inner points out.)  Levels at which no line of the call
         // can have an inner point -- the host's bound on y, engine.hip -- skip the look.
-        if (!(a.ablate & 32) && a.levels[level].inner_possible != 0.)
+        if (!LBL_ABLATED(a, 32) && a.levels[level].inner_possible != 0.)
         {
             // With the reference's cut-off of 25 cm-1 a line whose window clips the tile, or
             // whose wing covers it, is far from having its core there: only the core-range

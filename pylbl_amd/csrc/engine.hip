@@ -372,10 +372,6 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->timing = (int)value;
     }
-    else if (key == "interp_shape" && value >= 0 && value < 1000)
-    {
-        engine->interp_shape = (int)value;
-    }
     else if (key == "relax_launches" && (value == 0 || (value >= 2 && value <= 7)))
     {
         engine->relax_launches = (int)value;
@@ -384,29 +380,9 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->scan_chain = (int)value;
     }
-    else if (key == "order_runs" && (value == 0 || value == 1))
-    {
-        engine->order_runs = (int)value;
-    }
     else if (key == "skip_delivery_lanes" && (value == 0 || value == 1))
     {
         engine->skip_delivery_lanes = (int)value;
-    }
-    else if (key == "chain_first" && (value == 0 || value == 1))
-    {
-        engine->chain_first = (int)value;
-    }
-    else if (key == "item_order" && value >= 0 && value <= 2)
-    {
-        engine->item_order = (int)value;
-    }
-    else if (key == "item_floor" && value >= 0 && value <= 65536)
-    {
-        engine->item_floor = (int)value;
-    }
-    else if (key == "graphs" && (value == 0 || value == 1))
-    {
-        engine->graphs = (int)value;
     }
     else if (key == "overlap_plain" && (value == 0 || value == 1))
     {
@@ -432,10 +408,12 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     {
         engine->aligned_tiles = (int)value;
     }
+#ifdef LBL_ABLATE
     else if (key == "ablate" && value >= 0 && value <= 127)
     {
-        engine->ablate = (int)value;    // timing diagnostics only: results are wrong when set
+        engine->ablate = (int)value;    // diagnostics build only: results are wrong when set
     }
+#endif
     else if (key == "workspace_bytes" && value >= (1 << 20))
     {
         engine->workspace_bytes = value;

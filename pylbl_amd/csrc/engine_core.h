@@ -94,7 +94,6 @@ struct Molecule
     {
         int v0, vn, n_per_v, cut_off, points, aligned, farfield;
         int pieces = 1;         // the tiles in `pieces` runs of about equal weight (streamed calls)
-        int item_order = 0;     // engine option item_order the plan was built under
         int n_items = 0, n_split = 0;
         long long partial_slots = 0;
         DeviceBuffer<WorkItem> items;       // piece-major, heaviest first within a piece
@@ -124,29 +123,8 @@ enum { kTimePrepare = 0, kTimeSchedule = 1, kTimeAccumulate = 2, kTimePedestal =
 // One in-flight compute call: its own pair of streams and its own workspace, so that
 // several molecules can be in the pipeline at once (the serial pedestal chain of one
 // overlaps the accumulate kernels of the others, and its own).
-// A call on a tiny grid is three short dependent kernels (prologue -> accumulate -> combine) and its
-// cost is their launches: such calls replay an instantiated HIP graph of the three, kept per lane
-// and plan, whose kernel arguments are set afresh every call (engine option graphs).
-struct SmallGraph
-{
-    const void * plan = nullptr;        // Molecule::Plan it was built for (items, split tiles)
-    int count = 0, points = 0;
-    unsigned prologue_blocks = 0, items = 0, combine_blocks = 0;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipGraphNode_t prologue = nullptr, accumulate = nullptr, combine = nullptr;
-    void destroy()
-    {
-        if (exec != nullptr) (void)hipGraphExecDestroy(exec);
-        if (graph != nullptr) (void)hipGraphDestroy(graph);
-        exec = nullptr;
-        graph = nullptr;
-    }
-};
-
 struct Lane
 {
-    std::vector<SmallGraph> graphs;     // most recently used last, at most 8
     hipStream_t main = nullptr;     // prepare, schedule, accumulate, apply, copies
     hipStream_t side = nullptr;     // the pedestal pre-pass
     hipEvent_t prepared = nullptr, pedestal_done = nullptr, levels_copied = nullptr;
@@ -235,8 +213,6 @@ struct Lane
     void destroy()
     {
         drain();
-        for (auto & graph : graphs) graph.destroy();
-        graphs.clear();
         if (pinned_levels != nullptr) (void)hipHostFree(pinned_levels);
         pinned_levels = nullptr;
         if (prepared != nullptr) (void)hipEventDestroy(prepared);
@@ -426,18 +402,12 @@ struct lbl_engine
     int aligned_tiles = 0;          // measured: no gain at 0.001 cm-1
     int overlap_pedestal = 1;       // run the pedestal pre-pass beside the accumulate kernel
     int farfield = 0;               // sum distant lines by their power series (farfield.h)
-    int interp_shape = 0;           // continuum_interp_kernel<PT, LV> as 10 PT + LV, 0 = automatic
     int scan_chain = 1;             // pedestal chain by relaxation (pedestal.h), serial chain behind it
     int relax_launches = 0;         // relaxation launches before the serial chain (2 ... 7; 0: by the table)
-    int item_floor = 0;             // fewest lines per work item (0 = by grid size; experiments)
-    int item_order = 2;             // 0 exact weight, 1 weight classes in grid order, 2 ... dealt to the XCDs in paired stretches
     int lanes_in_use = 0;           // lanes the asynchronous calls rotate over; 0: by kind of call
-    int graphs = 0;                 // 1: calls on tiny grids replay a HIP graph of their three kernels
     long long small_points = 1ll << 20;    // grids (points x levels) up to this size count as small
     int overlap_plain = 1;          // plain asynchronous calls on larger grids take turns on two lanes too
-    int order_runs = 1;             // accumulate launch waits for the pedestal's run-finding kernels
     int skip_delivery_lanes = 1;    // delivering calls avoid lanes that share the copy stream's queue
-    int chain_first = 0;            // 1: far-field calls queue the pedestal chain before the accumulate launches (+-0)
 
     // Timing.
     struct Span { hipEvent_t begin, end; int kind, counts; };

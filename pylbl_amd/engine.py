@@ -86,7 +86,14 @@ def library():
     global _library
     if _library is not None:
         return _library
-    if not LIBRARY_PATH.exists():
+    path = LIBRARY_PATH
+    if os.environ.get("PYLBL_AMD_LIBRARY"):
+        # Another build of the same engine (sanitizer / diagnostics builds, A/B of two libraries):
+        # the shipped file is never overwritten to try one.
+        path = Path(os.environ["PYLBL_AMD_LIBRARY"]).resolve()
+        if not path.exists():
+            raise EngineError(f"$PYLBL_AMD_LIBRARY names {path}, which does not exist.")
+    elif not LIBRARY_PATH.exists():
         # A fresh checkout: compile in-tree (hipcc cross-compiles without a GPU).
         try:
             from . import build
@@ -96,7 +103,7 @@ def library():
                 f"{LIBRARY_PATH} is missing and could not be built ({error}); build it with "
                 "`python -m pylbl_amd.build` (there is no CPU fallback).")
     _preload_hip_runtime()
-    lib = CDLL(str(LIBRARY_PATH))
+    lib = CDLL(str(path))
     f64p, i32p, i64p = POINTER(c_double), POINTER(c_int32), POINTER(c_int64)
     lib.lbl_engine_create.argtypes = [c_int32, POINTER(c_void_p)]
     lib.lbl_engine_destroy.argtypes = [c_void_p]

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of one diagnostic switch on the same library: scripts/ab_ablate.sh <mask> [rounds]
 # prints ms/step and accumulate ms/step with --ablate 0 and --ablate <mask>, interleaved.
+# (parts of the kernel can only be switched off in the diagnostics build: python -m pylbl_amd.build ablate)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_ablate.so
 MASK=${1:-64}
 for round in $(seq 1 ${2:-2}); do
 for args in "--config target" "--config 1" "--config 2" "--levels-per-gpu 8 --profile standard" "--farfield"; do

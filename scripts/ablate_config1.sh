@@ -4,6 +4,8 @@
 # lines, 8 left-overs of the fast ranges, 16 core lines, 32 inner points, 64 clipped windows line
 # by line).  Results are wrong by construction; only the times matter ("launch alone": the mean
 # accumulate launch run by itself after the timed region, what profiles/r05_config1_where_the_time_goes.txt quotes).
+# (parts of the kernel can only be switched off in the diagnostics build: python -m pylbl_amd.build ablate)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_ablate.so
 TAG=${1:-r04}
 OUT=gpurun_out/ablate_config1_$TAG.txt
 : > $OUT

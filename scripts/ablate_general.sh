@@ -3,6 +3,8 @@
 # accumulate kernel switched off (engine option "ablate": 1 general ranges, 2 fast ranges,
 # 4 clipping lines, 8 left-overs of the fast ranges, 16 core lines).  Results are wrong by
 # construction; only ms_per_step matters.  Usage on the GPU box: scripts/ablate_general.sh <tag>
+# (parts of the kernel can only be switched off in the diagnostics build: python -m pylbl_amd.build ablate)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_ablate.so
 TAG=${1:-r02}
 OUT=gpurun_out/ablate_$TAG.txt
 : > $OUT

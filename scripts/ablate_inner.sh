@@ -2,6 +2,8 @@
 # Where the general path's time goes after the inner points moved into packed passes (engine
 # option "ablate": 1 no general ranges, 16 no core lines, 32 no inner points, 4 no clipping
 # lines; results are wrong by construction).  Usage on the GPU box: scripts/ablate_inner.sh <tag>
+# (parts of the kernel can only be switched off in the diagnostics build: python -m pylbl_amd.build ablate)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_ablate.so
 TAG=${1:-r03}
 OUT=gpurun_out/ablate_inner_$TAG.txt
 : > $OUT

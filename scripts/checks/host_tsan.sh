@@ -9,11 +9,10 @@
 # not instrumented, their locks are -- pthread calls are intercepted.)
 set -o pipefail
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.tsan-x86_64.so)
-cp pylbl_amd/liblbl_amd.so /tmp/lbl_plain.so
-cp pylbl_amd/liblbl_amd_tsan.so pylbl_amd/liblbl_amd.so
+# (the shipped library stays where it is: the engine loads the one $PYLBL_AMD_LIBRARY names)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_tsan.so
 export TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:log_path=gpurun_out/tsan
 LD_PRELOAD=$RT timeout -k 10 600 python -m pytest "${@:-tests/test_gpu_threads.py}" -x -q -m gpu -p no:cacheprovider
 rc=$?
-cp /tmp/lbl_plain.so pylbl_amd/liblbl_amd.so
 ls gpurun_out/tsan* 2>/dev/null && grep -h "WARNING\|SUMMARY" gpurun_out/tsan* | sort | uniq -c | sort -rn | head -30
 exit $rc

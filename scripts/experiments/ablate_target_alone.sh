@@ -1,6 +1,8 @@
 # The default workload (1 level, H2O + CO2, 5 M points), direct kernel: the accumulate launch run
 # alone with parts switched off (1 general ranges, 2 fast ranges, 4 clipping lines, 16 core lines,
 # 32 inner points).
+# (parts of the kernel can only be switched off in the diagnostics build: python -m pylbl_amd.build ablate)
+export PYLBL_AMD_LIBRARY=$(pwd)/pylbl_amd/liblbl_amd_ablate.so
 for ablate in 0 1 2 3 4 16 32 0; do
   python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --ablate $ablate 2>/dev/null | python -c "
 import sys, json

@@ -515,36 +515,6 @@ def test_lane_count_changes_nothing(remove_pedestal):
             engine.free(h)
 
 
-def test_small_calls_as_replayed_graphs_give_the_same_bits():
-    """Engine option graphs = 1: a call on a tiny grid replays one HIP graph (prologue ->
-    accumulate -> combine) with fresh kernel arguments instead of three launches.  (Off by default:
-    slower than the launches on ROCm 7.2)  Different levels, tables and output blocks
-    through the same cached graphs."""
-    from pylbl_amd.engine import DeviceSpectra, default_engine
-    engine = default_engine(0)
-    tables = [synthetic.line_table("CO2", 600., 700., num_lines=4000, seed=s) for s in (13, 14)]
-    handles = [engine.load(t) for t in tables]
-    v0, vn, npv = 620, 680, 20
-    n = (vn - v0)*npv
-    cases = [(h, t, p) for h in handles for t, p in ((240., 3e4), (290., 9e4), (200., 2e2))]
-    expected = [engine.compute(h, t, p, 4e-4, v0, vn, npv)[0].copy() for h, t, p in cases]
-    ring = [DeviceSpectra(engine, 1, n) for _ in range(len(cases))]
-    try:
-        engine.set_option("graphs", 1)
-        for sweep in range(3):
-            for (h, t, p), out in zip(cases, ring):
-                engine.compute(h, t, p, 4e-4, v0, vn, npv, out=out, asynchronous=True)
-        engine.synchronize()
-        for out, want in zip(ring, expected):
-            assert np.array_equal(out.to_host()[0], want)
-    finally:
-        engine.set_option("graphs", 0)
-        for block in ring:
-            block.free()
-        for h in handles:
-            engine.free(h)
-
-
 def test_row_copies_and_pinned_results():
     """lbl_copy_rows_to_host places device rows straight into a strided destination
     (beta[level, mechanism, :]); page-locked result arrays are recycled once dropped."""

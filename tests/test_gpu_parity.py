@@ -188,27 +188,6 @@ def test_seeded_against_oracle_fine_grid(engine, oracle, remove_pedestal, aligne
     engine.free(molecule)
 
 
-@pytest.mark.parametrize("farfield", [0, 1])
-def test_item_order_changes_no_bit(engine, farfield):
-    """The order work items are launched in (option item_order) is scheduling only: a dense
-    band that cuts its tiles into several items, every level, bit for bit."""
-    from pylbl_amd import synthetic
-    table = synthetic.banded_line_table("CO2", 400., 900., num_lines=120_000, bands=2, seed=77)
-    atmos = synthetic.fixture_atmosphere()
-    molecule = engine.load(table)
-    engine.set_option("farfield", farfield)
-    results = []
-    for order in (0, 1, 2):
-        engine.set_option("item_order", order)
-        results.append(engine.compute(molecule, atmos.t, atmos.p, atmos.vmr["CO2"],
-                                      400, 900, 200, remove_pedestal=True).copy())
-    engine.set_option("farfield", 0)
-    engine.free(molecule)
-    assert np.isfinite(results[0]).all() and results[0].max() > 0.
-    engine.set_option("item_order", 2)
-    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
-
-
 def test_unsorted_rows_and_skip_policy(engine, oracle):
     """Row order differs from wavenumber order; the reference rule stops at the first
     out-of-range row, the skip rule does not."""

@@ -88,8 +88,8 @@ def test_density_scaling_is_one_factor_per_level(engine, remove_pedestal):
 
 
 def test_a_call_has_no_memory(engine, level):
-    """Blocking and asynchronous calls (lane 0 / the two lanes plain calls take turns on), items in
-    either order, a different call in between: one set of bits."""
+    """Blocking and asynchronous calls (lane 0 / the two lanes plain calls take turns on), a
+    different call in between: one set of bits."""
     from pylbl_amd.engine import DeviceSpectra
     h2o = synthetic.line_table("H2O", 1., 5000.)
     co2 = synthetic.line_table("CO2", 1., 5000.)
@@ -97,11 +97,9 @@ def test_a_call_has_no_memory(engine, level):
     spectrum(engine, h2o, level, remove_pedestal=True, farfield=True)
     molecule = engine.load(co2)
     blocks = [DeviceSpectra(engine, 1, (VN - V0)*NPV) for _ in range(3)]
-    for order, block in zip((2, 0, 1), blocks):
-        engine.set_option("item_order", order)
+    for block in blocks:
         engine.compute(molecule, level.t, level.p, level.vmr["CO2"], V0, VN, NPV,
                        remove_pedestal=True, out=block, asynchronous=True)
-    engine.set_option("item_order", 2)
     engine.synchronize()
     for block in blocks:
         assert np.array_equal(block.to_host()[0], first)
