@@ -48,6 +48,14 @@ extern "C" {
 #define LBL_BAD_ARGUMENT    2
 #define LBL_NO_DEVICE       3   /* no usable gfx950 device / HIP runtime failure           */
 #define LBL_OUT_OF_RANGE    4   /* temperature outside the TIPS table, iso id without data  */
+/* lbl_table_read / lbl_molecule_load_sqlite: the first thing the file lacks for the molecule, in
+ * the order the reference looks things up (absorption.c:50-73) */
+#define LBL_TABLE_OPEN_FAILED       10  /* not an SQLite file this process can open            */
+#define LBL_TABLE_NO_ALIAS          11  /* spectral_database.c:152-156: the reference's rc 1    */
+#define LBL_TABLE_NO_TIPS           12  /* absorption.c:53-59: the reference returns zeros      */
+#define LBL_TABLE_NOT_RECTANGULAR   13  /* spectral_database.c:85-90                            */
+#define LBL_TABLE_NO_ISOTOPOLOGUES  14
+#define LBL_TABLE_NO_TRANSITIONS    15
 
 /* Which rows of the table take part (reference: pyLBL/c_lib/absorption.c:80-83). */
 #define LBL_RANGE_REFERENCE 0   /* stop at the first row outside [v0-(cut+1), vn+cut+1]    */
@@ -391,6 +399,32 @@ int absorption(double pressure, double temperature, double volume_mixing_ratio,
                int v0, int vn, int n_per_v, double *k, char *database, char *formula,
                int cut_off, int remove_pedestal);
 #endif
+
+/* The reader of lbl_absorption by itself -- no GPU involved: one molecule's rows out of an SQLite
+ * file in pyLBL's schema (database.py:418-486) through the reference C reader's own SELECTs
+ * (absorption.c:69-70; spectral_database.c:55, :113, :143), as host arrays.  Replaces, for hosts,
+ * the ORM route of pyLBL/database.py:350-395 (Database.gas / Database.tips) at the speed of the C
+ * row loop.  `name` is any alias of the molecule.  Status LBL_OK or LBL_TABLE_* (message:
+ * lbl_last_error(NULL)); *table is then NULL.
+ *   lbl_table_shape: row counts (transitions; isotopologue rows; TIPS isotopologues x temperatures),
+ *     the molecule's id and ordinary formula.
+ *   lbl_table_copy: copies out (any pointer may be NULL) the seven fp64 columns nu, sw, gamma_air,
+ *     gamma_self, n_air, elower, delta_air as columns[7][n_lines]; local_iso_id[n_lines] raw;
+ *     isoid / mass of the isotopologue rows in row order; tips_temperature[num_t];
+ *     tips_data[num_iso][num_t]. */
+typedef struct lbl_table lbl_table;
+int lbl_table_read(const char *path, const char *name, lbl_table **table);
+int lbl_table_shape(const lbl_table *table, int64_t *n_lines, int32_t *molecule_id,
+                    int32_t *n_isotopologues, int32_t *num_iso, int32_t *num_t,
+                    char *formula, int32_t formula_bytes);
+int lbl_table_copy(const lbl_table *table, double *columns, int32_t *local_iso_id,
+                   int64_t *isoid, double *mass, double *tips_temperature, double *tips_data);
+int lbl_table_free(lbl_table *table);
+
+/* File -> HBM in one call (read as above, masses filed under isoid with 0 -> 10, then
+ * lbl_molecule_load): what lbl_absorption does at its first call on a (path, formula). */
+int lbl_molecule_load_sqlite(lbl_engine *engine, const char *path, const char *name,
+                             int32_t *molecule);
 
 /* State of the compatibility entry: the device it computes on (-1 before its first call) and
  * the number of molecules it keeps in HBM. */

@@ -33,7 +33,8 @@ EXPORTED_SYMBOLS = (
     "lbl_device_alloc", "lbl_device_free", "lbl_copy_to_host",
     "lbl_copy_rows_to_host", "lbl_host_alloc", "lbl_host_free",
     "lbl_line_scalars", "lbl_absorption", "absorption", "lbl_compat_state", "lbl_fill_zero",
-    "lbl_version",
+    "lbl_version", "lbl_table_read", "lbl_table_shape", "lbl_table_copy", "lbl_table_free",
+    "lbl_molecule_load_sqlite",
     "lbl_continuum_load", "lbl_continuum_free", "lbl_grid_load", "lbl_grid_free",
     "lbl_continuum_compute", "lbl_continuum_compute_many", "lbl_continuum_bands",
     "lbl_xsec_load", "lbl_xsec_free", "lbl_xsec_compute", "lbl_xsec_bands",
@@ -140,6 +141,11 @@ def library():
                                   c_int32, c_int32]
     lib.absorption.argtypes = lib.lbl_absorption.argtypes
     lib.lbl_compat_state.argtypes = [i32p, i32p]
+    lib.lbl_table_read.argtypes = [c_char_p, c_char_p, POINTER(c_void_p)]
+    lib.lbl_table_shape.argtypes = [c_void_p, i64p, i32p, i32p, i32p, i32p, c_char_p, c_int32]
+    lib.lbl_table_copy.argtypes = [c_void_p] + [c_void_p]*6
+    lib.lbl_table_free.argtypes = [c_void_p]
+    lib.lbl_molecule_load_sqlite.argtypes = [c_void_p, c_char_p, c_char_p, i32p]
     lib.lbl_fill_zero.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32]
     lib.lbl_version.restype = c_char_p
     lib.lbl_continuum_load.argtypes = [c_void_p, c_int32, POINTER(BandDescriptor), c_void_p,
@@ -168,6 +174,44 @@ def library():
 
 def _f64(array):
     return np.ascontiguousarray(array, dtype=np.float64)
+
+
+# Status codes of lbl_table_read (include/lbl_amd.h).
+TABLE_OPEN_FAILED, TABLE_NO_ALIAS, TABLE_NO_TIPS, TABLE_NOT_RECTANGULAR, TABLE_NO_ISOTOPOLOGUES, \
+    TABLE_NO_TRANSITIONS = 10, 11, 12, 13, 14, 15
+
+
+def read_line_table(path, name):
+    """One molecule's rows out of an SQLite file in pyLBL's schema through the engine's own C
+    reader (lbl_table_read: the reference C reader's SELECTs, absorption.c:69-70,
+    spectral_database.c:55, :113, :143) -- no GPU involved.  Returns (status, message, fields):
+    status LBL_OK and a dict of arrays, or a TABLE_* status and the reader's message."""
+    from ctypes import create_string_buffer
+    lib = library()
+    table = c_void_p()
+    status = lib.lbl_table_read(os.fsencode(str(path)), str(name).encode(), byref(table))
+    if status != LBL_OK:
+        return status, lib.lbl_last_error(None).decode(), None
+    try:
+        n_lines, molecule_id = c_int64(), c_int32()
+        rows, num_iso, num_t = c_int32(), c_int32(), c_int32()
+        formula = create_string_buffer(256)
+        lib.lbl_table_shape(table, byref(n_lines), byref(molecule_id), byref(rows), byref(num_iso),
+                            byref(num_t), formula, 256)
+        columns = np.empty((7, n_lines.value))
+        local_iso_id = np.empty(n_lines.value, dtype=np.int32)
+        isoid = np.empty(rows.value, dtype=np.int64)
+        mass = np.empty(rows.value)
+        tips_temperature = np.empty(num_t.value)
+        tips_data = np.empty((num_iso.value, num_t.value))
+        lib.lbl_table_copy(table, columns.ctypes.data, local_iso_id.ctypes.data, isoid.ctypes.data,
+                           mass.ctypes.data, tips_temperature.ctypes.data, tips_data.ctypes.data)
+    finally:
+        lib.lbl_table_free(table)
+    return LBL_OK, "", {"formula": formula.value.decode(), "molecule_id": molecule_id.value,
+                        "columns": columns, "local_iso_id": local_iso_id, "isoid": isoid,
+                        "mass": mass, "tips_temperature": tips_temperature,
+                        "tips_data": tips_data}
 
 
 def _levels(values):
@@ -395,6 +439,16 @@ class Engine(object):
             self.handle, columns[0].size, *[x.ctypes.data for x in columns], iso.ctypes.data,
             mass.ctypes.data, tips_q.shape[0], tips_q.shape[1], tips_t.ctypes.data,
             tips_q.ctypes.data, byref(handle)))
+        return handle.value
+
+    def load_sqlite(self, path, name):
+        """File -> HBM in one call (lbl_molecule_load_sqlite): molecule `name` (any alias) of the
+        SQLite file at `path` in pyLBL's schema, read by the C reader and uploaded; returns the
+        molecule handle.  Raises EngineError with the reader's message when the file lacks
+        something (status LBL_TABLE_*, include/lbl_amd.h)."""
+        handle = c_int32(-1)
+        self._check(self.lib.lbl_molecule_load_sqlite(self.handle, os.fsencode(str(path)),
+                                                      str(name).encode(), byref(handle)))
         return handle.value
 
     def free(self, molecule):

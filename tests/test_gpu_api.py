@@ -128,6 +128,33 @@ def test_same_signature_c_entry(small_database, oracle):
         assert fn(98388., 288.99, 3.2e-7, v0, vn, npv, k, db.path.encode(), b"XYZ", 25, 0) == 1
 
 
+def test_file_to_hbm_in_one_call(small_database):
+    """lbl_molecule_load_sqlite (Engine.load_sqlite): the C reader of the same-signature entry on
+    an engine the host owns -- same bits as reading the table in Python and uploading it, and the
+    reader's statuses for what a file lacks."""
+    from pylbl_amd import engine as engine_module
+    from pylbl_amd.engine import default_engine
+    from pylbl_amd.errors import EngineError
+    engine = default_engine(0)
+    db, tables = small_database
+    t, p, x = np.asarray([288.99, 230.]), np.asarray([98388., 2.e4]), np.asarray([3.6e-4, 3.e-4])
+    direct = engine.load_sqlite(db.path, "CO2")
+    uploaded = engine.load(db.line_table("CO2"))
+    try:
+        for ped in (False, True):
+            a = engine.compute(direct, t, p, x, 1, 101, 20, remove_pedestal=ped).copy()
+            b = engine.compute(uploaded, t, p, x, 1, 101, 20, remove_pedestal=ped)
+            assert a.any() and np.array_equal(a, b)
+    finally:
+        engine.free(direct)
+        engine.free(uploaded)
+    for name, status in (("XYZ", engine_module.TABLE_NO_ALIAS), ("N2O", engine_module.TABLE_NO_TIPS)):
+        with pytest.raises(EngineError, match=f"status {status}"):
+            engine.load_sqlite(db.path, name)
+    with pytest.raises(EngineError, match=f"status {engine_module.TABLE_OPEN_FAILED}"):
+        engine.load_sqlite(db.path + ".missing", "CO2")
+
+
 def test_device_output_scale_and_accumulate(oracle):
     from pylbl_amd.engine import DeviceSpectra, Engine
     from pylbl_amd import number_density

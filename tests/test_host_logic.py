@@ -78,6 +78,56 @@ def test_database_without_tips_raises(tmp_path):
         database.Database(path).line_table("N2O")
 
 
+def test_c_reader_and_sqlite3_reader_return_the_same_table(tmp_path):
+    """Database.line_table goes through the engine library's C reader (lbl_table_read: the
+    reference C reader's SELECTs, absorption.c:69-70, spectral_database.c:55,113,143); the
+    standard-library route is what is left when the library cannot be loaded.  Same arrays, same
+    types, same exceptions -- on a file this package wrote and on the file the reference's ORM
+    wrote (tests/golden/refdb.db)."""
+    from pylbl_amd import engine
+    from pylbl_amd.errors import IsotopologuesNotFoundError, TransitionsNotFoundError
+    assert engine.read_line_table(str(tmp_path / "missing.db"), "CO2")[0] == engine.TABLE_OPEN_FAILED
+    tables = [synthetic.line_table("H2O", 1., 200., num_lines=300, seed=1, tips_range=(150, 350)),
+              synthetic.line_table("O3", 1., 200., num_lines=50, seed=3, tips_range=(150, 350))]
+    tables[1].local_iso_id[::7] = 0                 # HITRAN's tenth isotopologue, stored raw
+    own = database.write_database(tmp_path / "lines.db", tables, aliases={"H2O": ["water"]})
+    files = [(own, ["H2O", "water", "O3"])]
+    reference_file = ROOT / "tests" / "golden" / "refdb.db"
+    if reference_file.exists():
+        files.append((str(reference_file), database.Database(str(reference_file)).molecules()))
+    for path, names in files:
+        db = database.Database(path)
+        for name in names:
+            try:
+                slow = db._line_table_sqlite3(name)
+            except BaseException as error:          # (the reference's classes are BaseExceptions)
+                with pytest.raises(type(error)):
+                    db.line_table(name)
+                continue
+            fast = db.line_table(name)
+            assert fast.formula == slow.formula and fast.molecule_id == slow.molecule_id
+            for column in database.LINE_COLUMNS + ("local_iso_id", "isoid", "mass",
+                                                   "tips_temperature", "tips_data"):
+                a, b = getattr(fast, column), getattr(slow, column)
+                assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), column
+        for route in (db.line_table, db._line_table_sqlite3):
+            with pytest.raises(AliasNotFoundError):
+                route("no such molecule")
+    # What is missing is reported in the same order by both routes.
+    import sqlite3
+    for drop, error in (("isotopologue", IsotopologuesNotFoundError),
+                        ("transition", TransitionsNotFoundError), ("tips", TipsDataNotFoundError)):
+        path = database.write_database(tmp_path / f"without_{drop}.db", tables[:1])
+        connection = sqlite3.connect(path)
+        connection.execute(f"delete from {drop}")
+        connection.commit()
+        connection.close()
+        for route in (database.Database(path).line_table,
+                      database.Database(path)._line_table_sqlite3):
+            with pytest.raises(error):
+                route("H2O")
+
+
 def test_mass_slots_follow_hitran_counting():
     """isoid 0 is the tenth isotopologue (spectral_database.c:119-123)."""
     table = synthetic.line_table("O3", 1., 50., num_lines=10)
