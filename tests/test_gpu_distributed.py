@@ -82,6 +82,36 @@ def test_two_ranks_share_one_gpu(n_levels, output, ordering):
     _run_ranks(n_levels, output, "gloo", order_on_device=(ordering == "device"))
 
 
+def test_config3_shape_over_the_ranks_the_card_allows():
+    """BASELINE configs[3]'s partition -- the 64-level standard atmosphere, H2O + CO2 + O3, blocks
+    of levels per rank -- and configs[2]'s unit mode (one level, three molecules, the cross-rank
+    reduce) with FIVE child ranks on GPU 0 (the pool ends a run with more than six processes on
+    the card, and the test runner, which has computed on it, is one of them; the 8-way cut itself
+    is checked on the CPU, tests/test_distributed_gloo.py, and ranks 0 and 7 of 8 at full size
+    in tests/test_gpu_baseline_configs.py): 1-101 cm-1 at 0.001
+    cm-1, gloo, kernels and exchange ordered on the device.  Rank 0 compares two levels of every
+    rank's block with the oracle (tests/dist_config3_worker.py)."""
+    world = 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), PYLBL_AMD_ORDER_ON_DEVICE="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "dist_config3_worker.py"), "64"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for rank, proc in enumerate(procs):
+        try:
+            out, err = proc.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for other in procs:
+                other.kill()
+            raise
+        assert proc.returncode == 0 and f"rank {rank} ok" in out, out + err[-3000:]
+
+
 def _visible_gpus():
     """Counted without initialising HIP in the test process (the ranks are child processes)."""
     import torch
