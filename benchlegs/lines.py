@@ -289,7 +289,7 @@ def farfield_legs(job, line):
             roof["frac"] = issue.get("frac_of_issue_slots_at_measured_clock",
                                      issue["frac_of_issue_slots_at_2.4GHz"])
             roof["achieved"], roof["peak"] = roof["frac"], 1.0
-        for kernel in ("farfield_kernel", "farfield_group_kernel"):
+        for kernel in ("farfield_series_kernel",):
             counted, source = profiled_traffic(far_workload, kernel)
             if counted is not None:
                 roof.setdefault("series_kernels", {})[kernel] = {

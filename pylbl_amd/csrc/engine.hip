@@ -98,6 +98,7 @@ int lbl_engine_destroy(lbl_engine * engine)
         (void)hipEventDestroy(s.end);
     }
     for (auto & e : engine->event_pool) (void)hipEventDestroy(e);
+    if (engine->epoch != nullptr) (void)hipEventDestroy(engine->epoch);
     engine->molecules.clear();
     engine->groups.clear();
     engine->continua.clear();
@@ -370,6 +371,20 @@ int lbl_set_option(lbl_engine * engine, const char * name, int64_t value)
     }
     else if (key == "timing" && value >= 0 && value <= 2)
     {
+        if (value != 0 && engine->timing == 0)
+        {
+            // A fresh origin for the positions of the spans to come, behind everything queued so far.
+            try
+            {
+                HIP_TRY(hipSetDevice(engine->device));
+                engine->drain_lanes();
+                engine->reset_epoch();
+            }
+            catch (const HipFailure & f)
+            {
+                return fail(engine, LBL_ERROR, f.message);
+            }
+        }
         engine->timing = (int)value;
     }
     else if (key == "relax_launches" && (value == 0 || (value >= 2 && value <= 7)))
@@ -448,6 +463,17 @@ int lbl_timing(lbl_engine * engine, double ms[8], int64_t launches[8], int32_t r
             engine->time_ms[i] = 0.;
             engine->launches[i] = 0;
             engine->busy_ms[i] = 0.;
+        }
+    }
+    if (reset && engine->timing != 0)
+    {
+        try
+        {
+            engine->reset_epoch();      // (every stream has just been drained)
+        }
+        catch (const HipFailure & f)
+        {
+            return fail(engine, LBL_ERROR, f.message);
         }
     }
     return LBL_OK;

@@ -142,7 +142,7 @@ struct Lane
         bool pending = false;
         int pieces = 1, count = 0, n_cells = 0, flags = 0;
         long long point_begin[9] = {};      // piece p covers points [point_begin[p], point_begin[p+1])
-        int n_per_v = 0;
+        int n_per_v = 0, cut_off = 0;
         const double * sums = nullptr;
         long long sums_stride = 0;
         double * target = nullptr;
@@ -172,8 +172,6 @@ struct Lane
     DeviceBuffer<double> raw;       // un-pedestalled sums when the output must be added to
     DeviceBuffer<double> partial;   // partial sums of split tiles
     DeviceBuffer<double> far_series; // [levels][tiles][kFarTerms]
-    DeviceBuffer<double> far_group;  // [levels][groups][kFarParts][kFarTerms]
-    DeviceBuffer<GroupCuts> group_cuts;  // [levels][groups]
     DeviceBuffer<double> derived;
     DeviceBuffer<unsigned long long> evals;
     PedestalWorkspace pedestal;
@@ -415,6 +413,8 @@ struct lbl_engine
     std::vector<hipEvent_t> event_pool;
     double time_ms[kTimeKinds] = {};
     double busy_ms[kTimeKinds] = {};    // time during which AT LEAST ONE timed span of the kind ran
+    double busy_reach[kTimeKinds] = {}; // where the union of the kind's spans ends so far [ms from epoch]
+    hipEvent_t epoch = nullptr;         // origin of the spans' positions (reset_epoch)
     long long launches[kTimeKinds] = {};
 
     hipEvent_t take_event()
@@ -448,35 +448,43 @@ struct lbl_engine
 
     // Sums the spans' durations per kind (time_ms) and, because calls on different lanes run side
     // by side, also the length of the UNION of the spans of a kind on the device's clock (busy_ms:
-    // two launches that overlap count once) -- positions taken against the batch's first event.
+    // two launches that overlap count once).  Positions are milliseconds (double) from `epoch`, an
+    // event recorded on the engine's first stream when timing was last reset: it precedes every
+    // span on the device's clock, whichever lane a span ran on, and it is the same origin for every
+    // batch, so that the reach of the union carries over from one batch to the next (a launch that
+    // straddles a batch boundary is counted once).  A span whose position cannot be read (an event
+    // the runtime places before the epoch) is clamped to the epoch.
     void drain_spans()
     {
         if (spans.empty()) return;
-        std::vector<std::pair<float, float>> placed[kTimeKinds];
+        std::vector<std::pair<double, double>> placed[kTimeKinds];
         for (auto & s : spans) HIP_TRY(hipEventSynchronize(s.end));
-        const hipEvent_t origin = spans.front().begin;
+        if (epoch != nullptr) HIP_TRY(hipEventSynchronize(epoch));
         for (auto & s : spans)
         {
             float ms = 0.f, from = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, s.begin, s.end));
             time_ms[s.kind] += ms;
             launches[s.kind] += s.counts;
-            if (s.begin != origin) HIP_TRY(hipEventElapsedTime(&from, origin, s.begin));
-            placed[s.kind].push_back({from, from + ms});
+            if (epoch == nullptr || hipEventElapsedTime(&from, epoch, s.begin) != hipSuccess ||
+                !(from > 0.f))
+            {
+                (void)hipGetLastError();
+                from = 0.f;
+            }
+            placed[s.kind].push_back({(double)from, (double)from + (double)ms});
         }
         for (int kind = 0; kind < kTimeKinds; ++kind)
         {
             auto & list = placed[kind];
             std::sort(list.begin(), list.end());
-            float reach = 0.f;
-            bool open = false;
+            double & reach = busy_reach[kind];      // end of the union so far, carried over batches
             for (const auto & interval : list)
             {
-                if (!open || interval.first > reach)
+                if (interval.first > reach)
                 {
                     busy_ms[kind] += interval.second - interval.first;
                     reach = interval.second;
-                    open = true;
                 }
                 else if (interval.second > reach)
                 {
@@ -491,6 +499,14 @@ struct lbl_engine
             event_pool.push_back(s.end);
         }
         spans.clear();
+    }
+
+    // A fresh origin for the spans' positions (lbl_timing with reset, option "timing" switched on).
+    void reset_epoch()
+    {
+        if (epoch == nullptr) epoch = take_event();
+        HIP_TRY(hipEventRecord(epoch, stream));
+        for (int kind = 0; kind < kTimeKinds; ++kind) busy_reach[kind] = 0.;
     }
 
     void drain_lanes()
@@ -588,10 +604,11 @@ struct lbl_engine
                 HIP_TRY(hipStreamWaitEvent(f.finish_stream, lane.piece_summed[piece], 0));
             }
             dim3 grid((unsigned)((q1 - q0 + 255)/256), (unsigned)f.count);
-            hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256), 0, f.finish_stream, f.sums,
+            hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256),
+                               pedestal_apply_lds_bytes(f.cut_off), f.finish_stream, f.sums,
                                f.sums_stride, f.target, f.target_stride,
-                               lane.pedestal.cell_sum.data, lane.pedestal.point_sum.data,
-                               lane.levels.data, (int)q0, (int)q1, f.n_per_v, f.n_cells,
+                               lane.pedestal.bin_sum.data, lane.levels.data, (int)q0, (int)q1,
+                               f.n_per_v, f.n_cells + 2*f.cut_off + 3, f.cut_off,
                                (f.flags & LBL_SCALE_DENSITY) ? 1 : 0, f.add_into ? 1 : 0);
             HIP_TRY(hipGetLastError());
             if (f.streamed && q0 < f.columns)

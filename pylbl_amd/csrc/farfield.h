@@ -33,9 +33,9 @@ namespace lbl {
 // yet most of those lines are far enough away to be expanded about the centre of a GROUP of kFarGroup adjacent tiles just as well: a line at least
 // kFarRatio group half-widths from the group's centre (and beyond every core) converges at the
 // same rate over the whole group as a tile's lines do over the tile.  So
-//   farfield_group_kernel   per group: the very far lines, read once for kFarGroup tiles, and
-//                           the cut points that say which lines those are;
-//   farfield_kernel         per tile: what is left -- the lines between the tile's own limit
+//   per group (farfield_series_kernel, first half): the very far lines, read once for kFarGroup
+//                           tiles, and the cut points that say which lines those are;
+//   per tile (second half): what is left -- the lines between the tile's own limit
 //                           and the group's, and the few whose windows cover this tile but not
 //                           the whole group -- plus the group's polynomial re-centred on the
 //                           tile (a Taylor shift by the distance d of the two centres,
@@ -44,13 +44,6 @@ namespace lbl {
 // and the accumulate kernel evaluates one polynomial per point as before.  Reads and arithmetic
 // drop ~2.9x for kFarGroup = 4.
 constexpr int kFarGroup = 4;
-// A group's lines may be shared out over kFarParts workgroups whose sums the tile kernel adds in a
-// fixed order.  Measured (5 M points, 400 k lines): 1 part 28 us, 2 parts 35 us, 4 parts 70 us per
-// launch -- the kernels are bound by instruction issue (the 63 fp64 operations per line and the
-// reduction per wavefront), not by the length of a thread's walk, so more workgroups only add
-// reductions.
-constexpr int kFarParts = 1;
-
 // First index in [lo, hi] whose wavenumber is > x (ABOVE) or >= x, found by a whole wavefront: 64
 // probes per step, so ~3400 candidates take two loads' latency where a binary search takes
 // twelve (the search is the serial head of its workgroup).
@@ -148,24 +141,35 @@ __device__ __forceinline__ double series_of_lines(const LineWing * __restrict__ 
     return term;
 }
 
-// One 256-thread workgroup per (group, level, part).
-__global__ __launch_bounds__(256) void farfield_group_kernel(
+// One 256-thread workgroup per (group of kFarGroup tiles, level): first the series of the group's
+// very far lines about the group's centre (into LDS), then, tile by tile, what only the tile can
+// take -- the lines between the tile's own limit and the group's, and the few whose windows cover
+// this tile but not the whole group -- plus the group's polynomial re-centred on the tile.
+// (Rounds 3-5 ran the two steps as two launches, farfield_group_kernel and farfield_kernel, with
+// the group's cuts and series going through HBM in between; the sums are formed by the same
+// threads in the same order, so the coefficients are the same bits.)
+__global__ __launch_bounds__(256) void farfield_series_kernel(
     const LineWing * __restrict__ wing, const TileSchedule * __restrict__ schedule,
     const double * __restrict__ nu, const LevelScalars * __restrict__ levels, long long n_lines,
     Tiling tiling, int n_groups, int v0, int n_per_v, int n, double dv,
-    GroupCuts * __restrict__ cuts, double * __restrict__ group_series)
+    double * __restrict__ far_series)
 {
     __shared__ double wave_sum[4][kFarTerms];
     __shared__ GroupCuts shared_cuts;
+    __shared__ double group_term[kFarTerms];
     const int level = blockIdx.y;
-    const int group = blockIdx.x;
+    // Neighbouring groups read almost the same lines: one contiguous eighth of the spectrum per
+    // XCD (workgroup b runs on XCD b mod 8) keeps them in that XCD's L2 (speed only).
+    const int per_xcd = (n_groups + 7) >> 3;
+    const int group = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
     if (group >= n_groups)
     {
         return;
     }
     long long i0, i1;
     group_bounds(tiling, group, n_per_v, n, i0, i1);
-    const double u0 = tile_centre(v0, dv, i0, i1);
+    const double group_centre = tile_centre(v0, dv, i0, i1);
+    const int t0 = group*kFarGroup, t1 = min(t0 + kFarGroup, tiling.n_tiles);
     if (threadIdx.x < 128)
     {
         // The schedule's far limit (schedule_tile: cases 6 and 7) with the group's half width:
@@ -180,7 +184,6 @@ __global__ __launch_bounds__(256) void farfield_group_kernel(
                                       lv.shift_max + 1.e-9 : 0.;
         const double radius = fmax(kFarRatio*half, core + half)*(1. + 1.e-9) + 1.e-6;
         // Lines that cover every tile of the group: the tightest of the tiles' ranges.
-        const int t0 = group*kFarGroup, t1 = min(t0 + kFarGroup, tiling.n_tiles);
         int a1 = 0, a2 = (int)n_lines, f1 = (int)n_lines, f2 = 0;
         for (int t = t0; t < t1; ++t)
         {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void farfield_group_kernel(
         if (below)
         {
             const int g1 = bounded && f1 > a1
-                ? wave_search<true>(nu, a1, f1, u0 - radius - lv.shift_max) : a1;
+                ? wave_search<true>(nu, a1, f1, group_centre - radius - lv.shift_max) : a1;
             if (threadIdx.x == 0)
             {
                 shared_cuts.a1 = a1;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void farfield_group_kernel(
         else
         {
             const int g2 = bounded && a2 > f2
-                ? wave_search<false>(nu, f2, a2, u0 + radius + lv.shift_max) : a2;
+                ? wave_search<false>(nu, f2, a2, group_centre + radius + lv.shift_max) : a2;
             if (threadIdx.x == 64)
             {
                 shared_cuts.a2 = a2;
@@ -214,91 +217,87 @@ __global__ __launch_bounds__(256) void farfield_group_kernel(
         }
     }
     __syncthreads();
-    const GroupCuts gc = shared_cuts;
-    const int part = blockIdx.z;
-    if (threadIdx.x == 0 && part == 0)
+    // (wave-uniform: into scalar registers)
+    GroupCuts gc;
+    gc.a1 = __builtin_amdgcn_readfirstlane(shared_cuts.a1);
+    gc.g1 = __builtin_amdgcn_readfirstlane(shared_cuts.g1);
+    gc.g2 = __builtin_amdgcn_readfirstlane(shared_cuts.g2);
+    gc.a2 = __builtin_amdgcn_readfirstlane(shared_cuts.a2);
+    const LineWing * __restrict__ w = wing + (long long)level*n_lines;
+    // Job 0: the group's own series, about the group's centre; jobs 1 .. : the tiles of the group,
+    // each about its own centre.  One call site of series_of_lines for all of them (two of them
+    // cost the kernel twice the registers): a job is up to four index ranges laid end to end.
+#pragma unroll 1
+    for (int job = 0; job <= t1 - t0; ++job)
     {
-        cuts[(long long)level*n_groups + group] = gc;
-    }
-    const int left = max(gc.g1 - gc.a1, 0);
-    const int total = left + max(gc.a2 - gc.g2, 0);
-    const int share = (total + kFarParts - 1)/kFarParts;
-    const double term = series_of_lines(
-        wing + (long long)level*n_lines, min(part*share, total), min((part + 1)*share, total),
-        [&](int at) { return at < left ? gc.a1 + at : gc.g2 + (at - left); }, u0, wave_sum);
-    if (threadIdx.x < kFarTerms)
-    {
-        group_series[(((long long)level*n_groups + group)*kFarParts + part)*kFarTerms +
-                     threadIdx.x] = term;
-    }
-}
-
-// One 256-thread workgroup per (tile, level); thread = line (strided), then a block sum.
-__global__ __launch_bounds__(256) void farfield_kernel(const LineWing * __restrict__ wing,
-                                                       const TileSchedule * __restrict__ schedule,
-                                                       const GroupCuts * __restrict__ cuts,
-                                                       long long n_lines, Tiling tiling,
-                                                       const double * __restrict__ group_series,
-                                                       int n_groups, int v0, int n_per_v, int n,
-                                                       double dv,
-                                                       double * __restrict__ far_series)
-{
-    __shared__ double wave_sum[4][kFarTerms];
-    const int level = blockIdx.y;
-    // Neighbouring tiles read almost the same lines: one contiguous eighth of the spectrum
-    // per XCD keeps them in that XCD's L2 (speed only).
-    const int per_xcd = (tiling.n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiling.n_tiles)
-    {
-        return;
-    }
-    const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
-    const GroupCuts gc = cuts[(long long)level*n_groups + tile/kFarGroup];
-    long long i0, i1;
-    tile_bounds(tiling, tile, n_per_v, n, i0, i1);
-    const double u0 = tile_centre(v0, dv, i0, i1);
-    // This tile's far lines [a1, f1) and [f2, a2) without the group's [gc.a1, gc.g1), [gc.g2, gc.a2):
-    // four pieces laid end to end.
-    const int l1 = min(max(gc.a1, sc.a1), sc.f1);       // [a1, l1): cover this tile, not the group
-    const int l2 = min(max(gc.g1, l1), sc.f1);          // [l2, f1): nearer than the group's limit
-    const int r2 = max(min(gc.a2, sc.a2), sc.f2);       // [r2, a2)
-    const int r1 = max(min(gc.g2, r2), sc.f2);          // [f2, r1)
-    const int n0 = l1 - sc.a1, n1 = sc.f1 - l2, n2 = r1 - sc.f2, n3 = sc.a2 - r2;
-    const double own = series_of_lines(
-        wing + (long long)level*n_lines, 0, n0 + n1 + n2 + n3,
-        [&](int at) {
-            if (at < n0) return sc.a1 + at;
-            at -= n0;
-            if (at < n1) return l2 + at;
-            at -= n1;
-            if (at < n2) return sc.f2 + at;
-            return r2 + (at - n2);
-        }, u0, wave_sum);
-    if (threadIdx.x < kFarTerms)
-    {
-        // The group's polynomial in w = u + d about this tile's centre.
-        const int j = threadIdx.x;
-        long long g0, g1;
-        group_bounds(tiling, tile/kFarGroup, n_per_v, n, g0, g1);
-        const double d = u0 - tile_centre(v0, dv, g0, g1);
-        const double * __restrict__ gs =
-            group_series + ((long long)level*n_groups + tile/kFarGroup)*kFarParts*kFarTerms;
-        double shifted = 0., weight = 1.;       // weight = C(j+m, j) d^m
-#pragma unroll
-        for (int m = 0; m < kFarTerms; ++m)
+        int begin0, begin1, begin2, begin3, n0, n1, n2, n3;
+        double u0;
+        if (job == 0)
         {
-            if (j + m < kFarTerms)
+            begin0 = gc.a1; n0 = max(gc.g1 - gc.a1, 0);
+            begin1 = gc.g2; n1 = max(gc.a2 - gc.g2, 0);
+            begin2 = begin3 = 0; n2 = n3 = 0;
+            u0 = group_centre;
+        }
+        else
+        {
+            const int tile = t0 + job - 1;
+            const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
+            long long q0, q1;
+            tile_bounds(tiling, tile, n_per_v, n, q0, q1);
+            u0 = tile_centre(v0, dv, q0, q1);
+            // This tile's far lines [a1, f1) and [f2, a2) without the group's [gc.a1, gc.g1),
+            // [gc.g2, gc.a2): four pieces laid end to end.
+            const int l1 = min(max(gc.a1, sc.a1), sc.f1);       // [a1, l1): cover this tile, not the group
+            const int l2 = min(max(gc.g1, l1), sc.f1);          // [l2, f1): nearer than the group's limit
+            const int r2 = max(min(gc.a2, sc.a2), sc.f2);       // [r2, a2)
+            const int r1 = max(min(gc.g2, r2), sc.f2);          // [f2, r1)
+            begin0 = sc.a1; n0 = l1 - sc.a1;
+            begin1 = l2; n1 = sc.f1 - l2;
+            begin2 = sc.f2; n2 = r1 - sc.f2;
+            begin3 = r2; n3 = sc.a2 - r2;
+        }
+        const double own = series_of_lines(
+            w, 0, n0 + n1 + n2 + n3,
+            [&](int at) {
+                if (at < n0) return begin0 + at;
+                at -= n0;
+                if (at < n1) return begin1 + at;
+                at -= n1;
+                if (at < n2) return begin2 + at;
+                return begin3 + (at - n2);
+            }, u0, wave_sum);
+        if (threadIdx.x < kFarTerms)
+        {
+            const int j = threadIdx.x;
+            if (job == 0)
             {
-                const double * __restrict__ at = gs + j + m;
-                double term = at[0];
+                group_term[j] = own;
+            }
+            else
+            {
+                // The group's polynomial in w = u + d about this tile's centre.
+                const double d = u0 - group_centre;
+                double shifted = 0., weight = 1.;       // weight = C(j+m, j) d^m
+                // (the binomial factors depend on the thread alone: hidden from the optimiser, which
+                // would otherwise keep all 21 of them in registers around the loop over the jobs --
+                // 130 VGPRs instead of 70)
+                int row = j;
+                asm volatile("" : "+v"(row));
 #pragma unroll
-                for (int part = 1; part < kFarParts; ++part) term += at[part*kFarTerms];
-                shifted = __builtin_fma(term, weight, shifted);
-                weight *= d*((double)(j + m + 1)*(1./(double)(m + 1)));
+                for (int m = 0; m < kFarTerms; ++m)
+                {
+                    if (j + m < kFarTerms)
+                    {
+                        shifted = __builtin_fma(group_term[j + m], weight, shifted);
+                        weight *= d*((double)(row + m + 1)*(1./(double)(m + 1)));
+                    }
+                }
+                far_series[((long long)level*tiling.n_tiles + t0 + job - 1)*kFarTerms + j] =
+                    own + shifted;
             }
         }
-        far_series[((long long)level*tiling.n_tiles + tile)*kFarTerms + j] = own + shifted;
+        __syncthreads();    // group_term is complete / wave_sum has been read
     }
 }
 

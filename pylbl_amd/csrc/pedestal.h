@@ -22,13 +22,14 @@
 //    piecewise constant between integer wavenumbers, so the accumulate kernel subtracts one
 //    table value per grid point in its epilogue.
 //
-// Kernels: run_count / run_offset / run_compact (find runs in reference row order: a
-// three-pass parallel scan), run_sums (one wavefront per run: profile values on the run's
-// slots, in parallel over runs), run_prefix / run_links (the stretch of earlier runs that can
-// hold a run's end slots, and what they added there), run_relax (the recurrence in the runs'
-// pedestal totals as a triangular system: a few launches, each exact inside chunks of 64 runs), run_chain (one
-// wavefront per level: the serial form, for the levels the relaxation leaves),
-// pedestal_tables (per 1 cm-1 cell: total pedestal covering its interior / integer point).
+// Kernels (five launches, round 6; eleven to thirteen before): run_find (the runs in reference row
+// order, the prefix maxima of their bins: one single-pass scan), run_sums (one wavefront per run:
+// profile values on the run's slots, in parallel over runs), run_links (the stretch of earlier runs
+// that can hold a run's end slots, and what they added there), run_solve (the recurrence in the
+// runs' pedestal totals as a triangular system: a few sweeps inside one launch, each exact inside
+// chunks of 64 runs; the bins' totals; and, for the levels the sweeps leave, the serial form, one
+// wavefront per level), pedestal_apply (per point: the total pedestal of the windows that hold it,
+// summed from the bins' totals per 1 cm-1 cell, subtracted).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -96,33 +97,35 @@ struct RawBuffer
 
 struct PedestalWorkspace
 {
-    RawBuffer<int> block_count;     // [levels][blocks of kScanThreads rows]
+    RawBuffer<unsigned long long> scan[2];  // [levels][blocks of kScanThreads rows]: run_find_kernel's descriptors, used in turn
+    int scan_turn = 0;
     RawBuffer<int> run_start;       // [levels][n_lines]
+    RawBuffer<int> prefix_bin;      // [levels][n_lines]: running maximum of the runs' bins
     RawBuffer<int> run_count;       // [levels]
     RawBuffer<RunMeta> runs;        // [levels][max_runs]
     RawBuffer<double> slot_sums;    // [levels][max_runs][slot_stride]
     RawBuffer<RunLink> links;       // [levels][max_runs]
-    RawBuffer<double> pedestals[2]; // [levels][max_runs]: the relaxation's two sets of values
+    RawBuffer<double> pedestals;    // [sweeps][levels][max_runs]: every sweep's values
+    RawBuffer<int> progress;        // [levels][chunks of 64 runs]: sweeps completed
     RawBuffer<int2> run_slots;      // [levels][max_runs]: the runs' end slots, packed for the relaxation
     RawBuffer<int> run_bin;         // [levels][max_runs]
     RawBuffer<int> bin_end;         // [levels][bins]: 1 + the last run of every bin
-    RawBuffer<int> prefix_bin;      // [levels][max_runs]: running maximum of the runs' bins
-    RawBuffer<int> state;           // [levels][kChainState], see run_prefix_kernel
-    RawBuffer<double> slots;        // [levels][cells+1]       (only when LDS is too small)
-    RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]
-    RawBuffer<double> cell_sum;     // [levels][cells]
-    RawBuffer<double> point_sum;    // [levels][cells]
+    RawBuffer<int> bin_first;       // [levels][bins]: the first run of every bin
+    RawBuffer<int> state;           // [levels][kChainState], see pedestal_chain.h
+    RawBuffer<double> slots;        // [levels][cells+1]: the serial chain's slots of the spectrum
+    RawBuffer<double> bin_sum;      // [levels][cells+2*cut+3]: total pedestal of every window
     std::vector<int> host_counts;
 };
 
 constexpr int kRunCut = 1024;     // see opens_run
+constexpr int kPedestalSweepBuffers = 7;    // kMaxRelaxLaunches (pedestal_chain.h)
 
 inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cut_off)
 {
     const long long stride = 2*cut_off + 3;
     const long long runs = std::min<long long>(n_lines, 4ll*(n_cells + 2*cut_off + 2) + n_lines/kRunCut);
-    return n_lines*4 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 40) +
-           4ll*(n_cells + stride)*8;
+    return n_lines*8 + runs*((long long)(sizeof(RunMeta) + sizeof(RunLink)) + stride*8 + 16 +
+                             8ll*kPedestalSweepBuffers) + 4ll*(n_cells + stride)*8;
 }
 
 }  // namespace lbl
@@ -132,54 +135,66 @@ inline long long pedestal_bytes_per_level(long long n_lines, int n_cells, int cu
 
 namespace lbl {
 
-// One thread per 1 cm-1 cell: the interior points of cell c lie in the windows of bins
-// b = c+v0-cut .. c+v0+cut, its integer point also in bin c+v0-cut-1 (the window that closes
-// there).  Sums of non-negative totals in a fixed order: reproducible, and exactly zero where
-// no line reaches.
-__global__ __launch_bounds__(256) void pedestal_tables_kernel(GridSpec g, int n_cells, int n_bins,
-                                                              const double * __restrict__ bin_sum,
-                                                              double * __restrict__ cell_sum,
-                                                              double * __restrict__ point_sum)
-{
-    const int level = blockIdx.y;
-    const int cell = blockIdx.x*blockDim.x + threadIdx.x;
-    if (cell >= n_cells) return;
-    const double * bins = bin_sum + (long long)level*n_bins;
-    double interior = 0.;
-    for (int k = 1; k <= 2*g.cut_off + 1; ++k)
-    {
-        interior += bins[cell + k];
-    }
-    cell_sum[(long long)level*n_cells + cell] = interior;
-    point_sum[(long long)level*n_cells + cell] = interior + bins[cell];
-}
-
 // k = (sums - pedestal total of the windows holding the point) [* number density] [+ k].
-// Windows start and end on integer wavenumbers, so the total is constant inside a 1 cm-1
-// cell and has one extra bin of lines on the integer point that closes a window.
+// Windows start and end on integer wavenumbers, so the total is constant inside a 1 cm-1 cell and
+// has one extra bin of lines on the integer point that closes a window: the interior points of cell
+// c lie in the windows of bins c+1 .. c+2 cut_off+1 (bin b: the window of the lines with
+// floor(centre) = b + v0 - cut_off - 1), its integer point also in bin c (the window that closes
+// there).  Every workgroup forms the two totals of the (at most 256) cells its 256 points lie in
+// from the bins' totals, in LDS -- sums of non-negative totals in a fixed order: reproducible, and
+// exactly zero where no line reaches.  (Rounds 1-5 kept the two tables in HBM, written by a
+// launch of their own.)
 __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __restrict__ sums,
                                                              long long sums_stride,
                                                              double * __restrict__ out,
                                                              long long out_stride,
-                                                             const double * __restrict__ cell_sum,
-                                                             const double * __restrict__ point_sum,
+                                                             const double * __restrict__ bin_sum,
                                                              const LevelScalars * __restrict__ levels,
                                                              int first, int end, int n_per_v,
-                                                             int n_cells, int scale_density,
-                                                             int accumulate)
+                                                             int n_bins, int cut_off,
+                                                             int scale_density, int accumulate)
 {
     // Points [first, end): the whole grid, or the columns of one piece of a streamed call.
+    extern __shared__ double apply_lds[];
     const int level = blockIdx.y;
-    const int i = first + blockIdx.x*blockDim.x + threadIdx.x;
+    const int i_lo = first + blockIdx.x*256;
+    if (i_lo >= end) return;
+    const int i_hi = min(i_lo + 255, end - 1);
+    const int cell_lo = i_lo/n_per_v;
+    const int span = i_hi/n_per_v - cell_lo + 1;            // <= 256 cells
+    const int wanted = span + 2*cut_off + 1;                // bins cell_lo .. cell_hi + 2 cut_off + 1
+    double * bins = apply_lds;
+    double * cell_sum = apply_lds + 256 + 2*cut_off + 2;
+    double * point_sum = cell_sum + 256;
+    const double * source = bin_sum + (long long)level*n_bins + cell_lo;
+    for (int t = threadIdx.x; t < wanted; t += 256) bins[t] = source[t];
+    __syncthreads();
+    if ((int)threadIdx.x < span)
+    {
+        double interior = 0.;
+        for (int k = 1; k <= 2*cut_off + 1; ++k)
+        {
+            interior += bins[threadIdx.x + k];
+        }
+        cell_sum[threadIdx.x] = interior;
+        point_sum[threadIdx.x] = interior + bins[threadIdx.x];
+    }
+    __syncthreads();
+    const int i = i_lo + threadIdx.x;
     if (i >= end) return;
     const int cell = i/n_per_v;
     const bool on_integer = (cell*n_per_v == i);
-    const double * table = on_integer ? point_sum : cell_sum;
-    double value = sums[(long long)level*sums_stride + i] - table[(long long)level*n_cells + cell];
+    const double pedestal = on_integer ? point_sum[cell - cell_lo] : cell_sum[cell - cell_lo];
+    double value = sums[(long long)level*sums_stride + i] - pedestal;
     if (scale_density) value *= levels[level].density;
     double * k = out + (long long)level*out_stride;
     if (accumulate) value += k[i];
     k[i] = value;
+}
+
+inline size_t pedestal_apply_lds_bytes(int cut_off)
+{
+    return (size_t)(256 + 2*cut_off + 2 + 512)*sizeof(double);
 }
 
 // The pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are already in
@@ -192,35 +207,53 @@ inline void pedestal_check(hipError_t status, const char * what)
     }
 }
 
-// First half: finds the runs (three short scan kernels) and starts the copy of the run
-// counts to the host.  The engine orders them before the accumulate launch of the same call
-// (a resident accumulate grid of another call does not hold them up, see kScanThreads).
+// First half: finds the runs (one launch) and starts the copy of the run counts to the host.  The
+// engine orders it before the accumulate launch of the same call (a resident accumulate grid of
+// another call does not hold it up, see kScanThreads).
 inline void pedestal_find_runs(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
-                               const LineWing * wing, int count)
+                               const LineWing * wing, const GridSpec & g, int count, int n_cells,
+                               bool parallel_chain)
 {
     auto check = pedestal_check;
     const long long n_lines = t.n_lines;
     const int n_blocks = (int)((n_lines + kScanThreads - 1)/kScanThreads);
-    ws.block_count.reserve((size_t)count*n_blocks);
+    const int n_bins = n_cells + 2*g.cut_off + 3;
+    const size_t descriptors = (size_t)count*n_blocks;
+    if (descriptors > ws.scan[0].capacity)
+    {
+        // Fresh descriptor arrays start out clear; from then on every launch clears the array the
+        // next one uses.
+        for (auto & array : ws.scan)
+        {
+            array.reserve(descriptors);
+            check(hipMemsetAsync(array.data, 0, array.capacity*sizeof(unsigned long long), stream),
+                  "descriptor clear");
+        }
+    }
     ws.run_start.reserve((size_t)(count*n_lines));
+    ws.prefix_bin.reserve((size_t)(count*n_lines));
     ws.run_count.reserve((size_t)count);
-    hipLaunchKernelGGL(run_count_kernel, dim3(n_blocks, count), dim3(kScanThreads), 0, stream, wing,
-                       t.sorted_of_row, n_lines, n_blocks, ws.block_count.data);
-    hipLaunchKernelGGL(run_offset_kernel, dim3(count), dim3(kScanThreads), 0, stream, n_blocks,
-                       ws.block_count.data, ws.run_count.data);
-    hipLaunchKernelGGL(run_compact_kernel, dim3(n_blocks, count), dim3(kScanThreads), 0, stream, wing,
-                       t.sorted_of_row, n_lines, n_blocks, ws.block_count.data,
-                       ws.run_start.data);
-    check(hipGetLastError(), "run scan kernels");
+    ws.bin_sum.reserve((size_t)count*n_bins);
+    ws.bin_end.reserve((size_t)count*n_bins);
+    ws.bin_first.reserve((size_t)count*n_bins);
+    ws.state.reserve((size_t)count*kChainState);
+    unsigned long long * now = ws.scan[ws.scan_turn].data;
+    unsigned long long * next = ws.scan[ws.scan_turn ^ 1].data;
+    ws.scan_turn ^= 1;
+    hipLaunchKernelGGL(run_find_kernel, dim3(n_blocks, count), dim3(kScanThreads), 0, stream, wing,
+                       t.sorted_of_row, n_lines, n_blocks, g.v0 - g.cut_off - 1, now, next,
+                       (long long)ws.scan[0].capacity, ws.run_start.data, ws.prefix_bin.data,
+                       ws.run_count.data, n_bins, ws.bin_end.data, ws.bin_first.data,
+                       ws.bin_sum.data, ws.state.data, parallel_chain ? 1 : 0);
+    check(hipGetLastError(), "run_find_kernel");
     ws.host_counts.resize((size_t)count);
     check(hipMemcpyAsync(ws.host_counts.data(), ws.run_count.data, count*sizeof(int),
                          hipMemcpyDeviceToHost, stream), "run count copy");
 }
 
-// Second half: waits for the run counts, then sums, links, chain and tables on `stream`;
-// leaves cell_sum / point_sum for pedestal_apply_kernel.  parallel_chain: the relaxation
-// (run_relax_kernel) with the serial chain behind it for the levels it leaves; else the serial
-// chain alone.
+// Second half: waits for the run counts, then sums, links and the solve on `stream`; leaves bin_sum
+// for pedestal_apply_kernel.  parallel_chain: the relaxation (run_solve_kernel) with the serial
+// chain inside it for the levels it leaves; else the serial chain alone.
 inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const LineTableView & t,
                             const LineWing * wing, const LineCore * core, const GridSpec & g,
                             int count, int n_cells, bool parallel_chain = true, int relax_launches = 0)
@@ -229,11 +262,6 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     const long long n_lines = t.n_lines;
     const int slot_stride = 2*g.cut_off + 3;
     const int n_bins = n_cells + 2*g.cut_off + 3;
-    ws.bin_sum.reserve((size_t)count*n_bins);
-    ws.bin_end.reserve((size_t)count*n_bins);
-    ws.cell_sum.reserve((size_t)count*n_cells);
-    ws.point_sum.reserve((size_t)count*n_cells);
-    ws.state.reserve((size_t)count*kChainState);
     // (Sizing the pass by a host-side bound on the runs instead -- no wait here -- was built twice,
     // rounds 3 and 4: the user-facing call gains 1 % at most, calls queued in numbers lose the
     // pacing this wait gives them: profiles/r03_ab_prepass.txt, r04_ab_total_order.txt.  Reading the
@@ -242,11 +270,18 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
     // profiles/r04_ab_pinned_counts.txt.)
     check(hipStreamSynchronize(stream), "run count sync");
     int max_runs = 1;
-    for (int c : ws.host_counts) max_runs = std::max(max_runs, c);
-    // How many relaxation launches to queue (0: by the table): three settle every table whose runs
-    // are about as many as its windows; where dozens of lines alternate between two windows at
-    // every integer wavenumber (a 4 M-line table: three runs per window) chains cross more chunk
-    // boundaries and five are needed.  Every launch is ~6 us of the host's time, used or not.
+    for (int c : ws.host_counts)
+    {
+        if (c < 0 || c > n_lines)
+        {
+            throw std::runtime_error("the scan for the pedestal's runs did not complete.");
+        }
+        max_runs = std::max(max_runs, c);
+    }
+    // How many sweeps of the relaxation (0: by the table): three settle every table whose runs are
+    // about as many as its windows; where dozens of lines alternate between two windows at every
+    // integer wavenumber (a 4 M-line table: three runs per window) chains cross more chunk
+    // boundaries and five are needed.
     if (relax_launches <= 0) relax_launches = max_runs > 2*n_bins ? 5 : 3;
     relax_launches = std::min(std::max(relax_launches, 2), kMaxRelaxLaunches);
     ws.runs.reserve((size_t)count*max_runs);
@@ -256,42 +291,40 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
                        ws.run_start.data, ws.run_count.data, max_runs, slot_stride,
                        ws.runs.data, ws.slot_sums.data);
     check(hipGetLastError(), "run_sums_kernel");
-    ws.prefix_bin.reserve((size_t)count*max_runs);
-    hipLaunchKernelGGL(run_prefix_kernel, dim3(count), dim3(kScanThreads), 0, stream,
-                       ws.run_count.data, max_runs, n_bins, ws.runs.data, ws.prefix_bin.data,
-                       ws.bin_end.data, ws.bin_sum.data, ws.state.data, parallel_chain ? 1 : 0,
-                       relax_launches);
+    // The serial chain in its small-LDS form (slots of the spectrum in HBM, the active ones in
+    // registers and a ring in LDS): 15.5 KB, less than one accumulate workgroup holds.
+    const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
+    const size_t ring_bytes = (size_t)kChainRing*sizeof(double);
     if (parallel_chain)
     {
+        const int max_chunks = (max_runs + 63)/64;
         ws.links.reserve((size_t)count*max_runs);
         ws.run_slots.reserve((size_t)count*max_runs);
         ws.run_bin.reserve((size_t)count*max_runs);
-        ws.pedestals[0].reserve((size_t)count*max_runs);
-        ws.pedestals[1].reserve((size_t)count*max_runs);
+        ws.pedestals.reserve((size_t)relax_launches*count*max_runs);
+        ws.progress.reserve((size_t)count*max_chunks);
+        ws.slots.reserve((size_t)count*(n_cells + 1));
         hipLaunchKernelGGL(run_links_kernel, dim3(std::min(max_runs, 65535), count), dim3(64), 0,
                            stream, ws.run_count.data, max_runs, slot_stride, n_bins, ws.runs.data,
-                           ws.slot_sums.data, ws.prefix_bin.data, ws.bin_end.data, ws.links.data,
+                           ws.slot_sums.data, ws.prefix_bin.data, n_lines, ws.bin_end.data,
+                           ws.bin_first.data, ws.progress.data, max_chunks, ws.links.data,
                            ws.run_slots.data, ws.run_bin.data, ws.state.data);
-        const dim3 chunks((max_runs + 63)/64, count);
-        for (int launch = 0; launch < relax_launches; ++launch)
-        {
-            hipLaunchKernelGGL(run_relax_kernel, chunks, dim3(64), 0, stream, ws.run_count.data,
-                               max_runs, n_bins, launch, ws.links.data, ws.run_slots.data,
-                               ws.run_bin.data, ws.bin_end.data,
-                               ws.pedestals[(launch + 1) & 1].data, ws.pedestals[launch & 1].data,
-                               ws.state.data, ws.bin_sum.data);
-        }
-        check(hipGetLastError(), "run_relax_kernel");
+        check(hipGetLastError(), "run_links_kernel");
+        // Windows of at most 64 slots (cut_off <= 30) keep the active slots in registers.
+        auto solve = slot_stride <= 64 ? run_solve_kernel<true> : run_solve_kernel<false>;
+        hipLaunchKernelGGL(solve, dim3(max_chunks, count), dim3(64), staged_bytes + ring_bytes,
+                           stream, ws.run_count.data, max_runs, max_chunks, n_bins, relax_launches,
+                           ws.links.data, ws.run_slots.data, ws.run_bin.data, ws.bin_end.data,
+                           ws.bin_first.data, ws.pedestals.data, (long long)count*max_runs,
+                           ws.progress.data, ws.state.data, ws.bin_sum.data, slot_stride, g,
+                           n_cells, ws.runs.data, ws.slot_sums.data, ws.slots.data);
+        check(hipGetLastError(), "run_solve_kernel");
+        return;
     }
-    // The serial chain takes the levels the relaxation left (rows far out of order; or not settled
-    // after the last launch: chains of dependences across many chunks of runs).  Behind the
-    // relaxation it is launched in its small-LDS form (slots of the spectrum in HBM, the active
-    // ones in registers): it usually only looks at the flags and returns, and must not queue for
-    // most of a CU's LDS to do that (the accumulate workgroups beside it hold 12-27 KB each).
-    const size_t staged_bytes = (size_t)2*kChainChunk*slot_stride*sizeof(double);
-    const size_t ring_bytes = (size_t)kChainRing*sizeof(double);
+    // The serial chain alone (engine option scan_chain = 0): slots and bin totals in LDS where they
+    // fit, else in HBM.
     const size_t lds_bytes = staged_bytes + (size_t)(n_cells + 1 + n_bins)*sizeof(double);
-    if (lds_bytes <= 160*1024 - 512 && !parallel_chain)
+    if (lds_bytes <= 160*1024 - 512)
     {
         if (lds_bytes > 64*1024)
         {
@@ -302,12 +335,10 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_bytes), "LDS opt-in");
         }
-        // Windows of at most 64 slots (cut_off <= 30) keep the active slots in registers.
         auto chain = slot_stride <= 64 ? run_chain_kernel<true, true> : run_chain_kernel<true, false>;
         hipLaunchKernelGGL(chain, dim3(count), dim3(64), lds_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, ws.state.data, (double *)nullptr,
-                           ws.bin_sum.data);
+                           ws.runs.data, ws.slot_sums.data, (double *)nullptr, ws.bin_sum.data);
     }
     else
     {
@@ -315,14 +346,9 @@ inline void pedestal_finish(PedestalWorkspace & ws, hipStream_t stream, const Li
         auto chain = slot_stride <= 64 ? run_chain_kernel<false, true> : run_chain_kernel<false, false>;
         hipLaunchKernelGGL(chain, dim3(count), dim3(64), staged_bytes + ring_bytes, stream,
                            ws.run_count.data, max_runs, slot_stride, g, n_cells, n_bins,
-                           ws.runs.data, ws.slot_sums.data, ws.state.data, ws.slots.data,
-                           ws.bin_sum.data);
+                           ws.runs.data, ws.slot_sums.data, ws.slots.data, ws.bin_sum.data);
     }
     check(hipGetLastError(), "run_chain_kernel");
-    hipLaunchKernelGGL(pedestal_tables_kernel, dim3((n_cells + 255)/256, count), dim3(256), 0,
-                       stream, g, n_cells, n_bins, ws.bin_sum.data, ws.cell_sum.data,
-                       ws.point_sum.data);
-    check(hipGetLastError(), "pedestal_tables_kernel");
 }
 
 }  // namespace lbl

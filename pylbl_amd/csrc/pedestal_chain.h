@@ -45,83 +45,29 @@ namespace lbl {
 // of this kept bit masks over the previous 256 runs and gave up beyond.)  What still costs
 // launches is a chain that matters ACROSS chunks: one launch per boundary it crosses.
 // ---------------------------------------------------------------------------------------
-// Per level: [0] 1 while the relaxation applies (cleared by run_links_kernel where rows are too far
-// out of order, by the first relaxation launch where one window's runs are spread over more than
-// kMaxStretch runs: its total would be one lane's walk of thousands), [k] something
-// changed in relaxation launch k (k = 1 .. launches-1), [7] the number of launches queued.
-constexpr int kChainState = 8;
+// Per level (kChainState ints, reset by run_find_kernel): [0] 1 while the relaxation applies
+// (cleared by run_links_kernel where rows are too far out of order, by the first sweep where one
+// window's runs are spread over more than kMaxStretch runs: its total would be one lane's walk of
+// thousands, and by a chunk whose wait for an earlier chunk ran out), [k] something changed in
+// sweep k (k = 1 .. sweeps-1), [8] chunks of the level that have left run_solve_kernel.
 constexpr int kMaxRelaxLaunches = 7;
 constexpr int kMaxStretch = 1024;
 constexpr int kMaxHistory = 16384;  // earlier runs a run may have to look at (a 4 M-line table: 1 800)
+constexpr int kStateFinished = 8;
 
-// A launch that changed nothing has verified the values it was handed.
-__device__ __forceinline__ bool chain_verified_before(const int * state, int launch)
+// A sweep that changed nothing has verified the values it was handed.
+__device__ __forceinline__ bool chain_verified_before(const int * state, int sweep)
 {
-    for (int k = 1; k < launch; ++k)
+    for (int k = 1; k < sweep; ++k)
     {
         if (state[k] == 0) return true;
     }
     return false;
 }
 
-__device__ __forceinline__ bool chain_settled(const int * state)
+__device__ __forceinline__ bool chain_settled(const int * state, int sweeps)
 {
-    return state[0] != 0 && chain_verified_before(state, state[kChainState - 1]);
-}
-
-// prefix_bin[r] = max over q <= r of the runs' bins (one workgroup per level: every thread takes
-// a contiguous share of the runs, the shares' maxima are scanned, the shares written back).
-// Also resets the level's chain state and clears what the relaxation fills: bin_end (1 + the
-// last run of every bin, run_links_kernel) and bin_sum (bins without a run keep zero).
-__global__ __launch_bounds__(kScanThreads) void run_prefix_kernel(const int * __restrict__ run_count,
-                                                          int max_runs, int n_bins,
-                                                          const RunMeta * __restrict__ runs,
-                                                          int * __restrict__ prefix_bin,
-                                                          int * __restrict__ bin_end,
-                                                          double * __restrict__ bin_sum,
-                                                          int * __restrict__ state, int start_state,
-                                                          int launches)
-{
-    __shared__ int wave_max[kScanThreads/64];
-    const int level = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int count = run_count[level];
-    const RunMeta * meta = runs + (long long)level*max_runs;
-    int * out = prefix_bin + (long long)level*max_runs;
-    if (start_state != 0)
-    {
-        for (int b = threadIdx.x; b < n_bins; b += kScanThreads)
-        {
-            bin_end[(long long)level*n_bins + b] = 0;
-            bin_sum[(long long)level*n_bins + b] = 0.;
-        }
-    }
-    if (threadIdx.x < kChainState)
-    {
-        state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state
-                                                 : threadIdx.x == kChainState - 1 ? launches : 0;
-    }
-    const int share = (count + kScanThreads - 1)/kScanThreads;
-    const int begin = min(threadIdx.x*share, count), end = min(begin + share, count);
-    int mine = -1;
-    for (int r = begin; r < end; ++r) mine = max(mine, meta[r].bin);
-    int scan = mine;
-    for (int offset = 1; offset < 64; offset <<= 1)
-    {
-        const int up = __shfl_up(scan, offset, 64);
-        if (lane >= offset) scan = max(scan, up);
-    }
-    if (lane == 63) wave_max[wave] = scan;
-    __syncthreads();
-    int before = -1;
-    for (int i = 0; i < wave; ++i) before = max(before, wave_max[i]);
-    const int up = __shfl_up(scan, 1, 64);
-    int running = max(before, lane > 0 ? up : -1);      // everything before this thread's share
-    for (int r = begin; r < end; ++r)
-    {
-        running = max(running, meta[r].bin);
-        out[r] = running;
-    }
+    return state[0] != 0 && chain_verified_before(state, sweeps);
 }
 
 // First index in [lo, hi) whose value is >= x in a non-decreasing array, found by a whole
@@ -153,7 +99,10 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
                                                        const RunMeta * __restrict__ runs,
                                                        const double * __restrict__ slot_sums,
                                                        const int * __restrict__ prefix_bin,
+                                                       long long prefix_stride,
                                                        int * __restrict__ bin_end,
+                                                       int * __restrict__ bin_first,
+                                                       int * __restrict__ progress, int max_chunks,
                                                        RunLink * __restrict__ links,
                                                        int2 * __restrict__ run_slots,
                                                        int * __restrict__ run_bin,
@@ -164,7 +113,7 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
     const int count = run_count[level];
     const RunMeta * meta = runs + (long long)level*max_runs;
     const double * sums = slot_sums + (long long)level*max_runs*slot_stride;
-    const int * prefix = prefix_bin + (long long)level*max_runs;
+    const int * prefix = prefix_bin + (long long)level*prefix_stride;
     for (int r = blockIdx.x; r < count; r += gridDim.x)
     {
         const RunMeta m = meta[r];
@@ -216,7 +165,13 @@ __global__ __launch_bounds__(64) void run_links_kernel(const int * __restrict__ 
             // Rows too far out of order for the stretch to be what it is taken for.
             const bool displaced = !bin_ok || (r > 0 && prefix[r - 1] > m.bin + 1);
             if (displaced || too_long) atomicAnd(&state[level*kChainState], 0);
-            if (bin_ok) atomicMax(&bin_end[(long long)level*n_bins + m.bin], r + 1);
+            if (bin_ok)
+            {
+                atomicMax(&bin_end[(long long)level*n_bins + m.bin], r + 1);
+                atomicMin(&bin_first[(long long)level*n_bins + m.bin], r);
+            }
+            // (the sweeps this chunk of 64 runs has completed: run_solve_kernel)
+            if ((r & 63) == 0) progress[(long long)level*max_chunks + (r >> 6)] = 0;
             RunLink link;
             link.ks = gs + m.vs;
             link.ke = ge + m.ve;
@@ -239,124 +194,6 @@ __device__ __forceinline__ double run_pedestal(double k_s, double k_e, int n_slo
     return (n_slots == 1 || !(k_s - k_e > 0.)) ? k_s : k_e;
 }
 
-constexpr int kHistoryTile = 256;   // earlier runs staged in LDS at a time
-
-// One wavefront per 64 consecutive runs (lane = run).  Inside the chunk the system is solved
-// exactly, run by run (forward substitution: run t's value is broadcast, the later lanes whose
-// masks name it add it to their sums -- ~20 instructions a step); what earlier chunks hold comes
-// from the previous launch (launch 0: zero): the stretch of runs from the first that can hold a
-// slot of this chunk up to the chunk, staged through LDS, oldest first, every lane testing the run
-// against its own two end slots.  So launch k is exact for every chain of dependences that
-// crosses at most k chunk boundaries, whatever its length inside a chunk (the runs of the
-// 2 cut_off + 2 windows clipped at either end of the grid form such chains: each holds the end
-// slot of all the others).  Launches >= 1 report a change and sum the bins' totals from the
-// values they were handed -- final if the launch changes nothing anywhere.
-__global__ __launch_bounds__(64) void run_relax_kernel(const int * __restrict__ run_count,
-                                                       int max_runs, int n_bins, int launch,
-                                                       const RunLink * __restrict__ links,
-                                                       const int2 * __restrict__ run_slots,
-                                                       const int * __restrict__ run_bin,
-                                                       const int * __restrict__ bin_end,
-                                                       const double * __restrict__ p_in,
-                                                       double * __restrict__ p_out,
-                                                       int * __restrict__ state,
-                                                       double * __restrict__ bin_sum)
-{
-    __shared__ double history_p[kHistoryTile];
-    __shared__ int2 history_slots[kHistoryTile];
-    const int level = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int count = run_count[level];
-    const int base = blockIdx.x*64;
-    int * flags = state + level*kChainState;
-    if (base >= count || flags[0] == 0) return;
-    if (chain_verified_before(flags, launch)) return;       // an earlier launch changed nothing
-    const double * from = p_in + (long long)level*max_runs;
-    const int2 * slots_of = run_slots + (long long)level*max_runs;
-    const int r = base + lane;
-    const bool valid = r < count;
-    RunLink mine;
-    mine.ks = mine.ke = 0.;
-    mine.in_s = mine.in_e = 0ull;
-    mine.bin = -1; mine.n_slots = 0; mine.begin = base; mine.first_of_bin = 0;
-    int2 ends = make_int2(-1, -1);
-    if (valid)
-    {
-        mine = links[(long long)level*max_runs + r];
-        ends = slots_of[r];
-    }
-    double given = 0., before_s = 0., before_e = 0.;
-    if (launch > 0 && valid) given = from[r];
-    if (launch > 0 && base > 0)
-    {
-        // The earliest run any lane of the chunk looks back to.
-        int oldest = min(mine.begin, base);
-        for (int offset = 32; offset > 0; offset >>= 1)
-        {
-            oldest = min(oldest, __shfl_xor(oldest, offset, 64));
-        }
-        for (int tile = oldest; tile < base; tile += kHistoryTile)
-        {
-            const int length = min(kHistoryTile, base - tile);
-            __builtin_amdgcn_wave_barrier();        // the previous tile has been read
-            for (int t = lane; t < length; t += 64)
-            {
-                history_p[t] = from[tile + t];
-                history_slots[t] = slots_of[tile + t];
-            }
-            __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
-            for (int t = 0; t < length; ++t)
-            {
-                const double value = history_p[t];
-                const int2 window = history_slots[t];
-                if (window.x <= ends.x && ends.x <= window.y) before_s += value;
-                if (window.x <= ends.y && ends.y <= window.y) before_e += value;
-            }
-        }
-    }
-    // The chunk itself: run t of the chunk is bit lane-1-t of the later lanes' masks.
-    double p = 0.;
-    const int last = min(64, count - base);
-    for (int t = 0; t < last; ++t)
-    {
-        const double candidate = run_pedestal(mine.ks - before_s, mine.ke - before_e, mine.n_slots);
-        const double settled = read_lane(candidate, t);
-        if (lane == t) p = candidate;
-        const int j = lane - 1 - t;
-        if (j >= 0)
-        {
-            if ((mine.in_s >> j) & 1ull) before_s += settled;
-            if ((mine.in_e >> j) & 1ull) before_e += settled;
-        }
-    }
-    if (valid) p_out[(long long)level*max_runs + r] = p;
-    if (launch == 0 && valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins &&
-        bin_end[(long long)level*n_bins + mine.bin] - r > kMaxStretch)
-    {
-        atomicAnd(&flags[0], 0);
-    }
-    if (launch > 0)
-    {
-        const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
-        if (__ballot(moved) != 0ull && lane == 0)
-        {
-            atomicOr(&flags[launch], 1);        // (run_prefix_kernel cleared the flags)
-        }
-        if (valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins)
-        {
-            // The bin's total of the values handed in: its runs in row order, up to its last.
-            const int * bins = run_bin + (long long)level*max_runs;
-            const int end = bin_end[(long long)level*n_bins + mine.bin];
-            double total = 0.;
-            for (int q = r; q < end; ++q)
-            {
-                if (bins[q] == mine.bin) total += from[q];
-            }
-            bin_sum[(long long)level*n_bins + mine.bin] = total;
-        }
-    }
-}
-
 constexpr int kChainChunk = 16;     // runs whose slot sums are staged in LDS at a time
 // Small-LDS form: the slots of the spectrum live in HBM, kChainRing consecutive ones of them in LDS
 // (the register window moves inside that ring at the price of an LDS round trip; only when it
@@ -371,19 +208,14 @@ constexpr int kChainRingBack = 64;  // slots kept behind the window that re-base
 // inputs of the next kChainChunk runs are staged cooperatively so that no global-memory
 // latency sits on the serial chain.
 template <bool USE_LDS, bool WINDOW>
-__global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ run_count,
-                                                       int max_runs, int slot_stride,
-                                                       GridSpec g, int n_cells, int n_bins,
-                                                       const RunMeta * __restrict__ runs,
-                                                       const double * __restrict__ slot_sums,
-                                                       const int * __restrict__ state,
-                                                       double * __restrict__ global_slots,
-                                                       double * __restrict__ bin_sum)
+__device__ __forceinline__ void run_chain(int level, const int * __restrict__ run_count,
+                                          int max_runs, int slot_stride, GridSpec g, int n_cells,
+                                          int n_bins, const RunMeta * __restrict__ runs,
+                                          const double * __restrict__ slot_sums,
+                                          double * __restrict__ global_slots,
+                                          double * __restrict__ bin_sum, double * lds)
 {
-    extern __shared__ double lds[];
-    const int level = blockIdx.x;
     const int lane = threadIdx.x;
-    if (state != nullptr && chain_settled(state + level*kChainState)) return;   // relaxation did it
     __builtin_amdgcn_s_setprio(3);
     // LDS carve: [2 x staged slot sums][slots][bin sums]; without LDS room the last two are in HBM.
     double * staged = lds;
@@ -593,6 +425,252 @@ __global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ 
     {
         for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = bins[s];
     }
+}
+
+// The serial chain by itself, one wavefront per level (engine option scan_chain = 0).
+template <bool USE_LDS, bool WINDOW>
+__global__ __launch_bounds__(64) void run_chain_kernel(const int * __restrict__ run_count,
+                                                       int max_runs, int slot_stride,
+                                                       GridSpec g, int n_cells, int n_bins,
+                                                       const RunMeta * __restrict__ runs,
+                                                       const double * __restrict__ slot_sums,
+                                                       double * __restrict__ global_slots,
+                                                       double * __restrict__ bin_sum)
+{
+    extern __shared__ double chain_lds[];
+    run_chain<USE_LDS, WINDOW>(blockIdx.x, run_count, max_runs, slot_stride, g, n_cells, n_bins,
+                               runs, slot_sums, global_slots, bin_sum, chain_lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The relaxation in ONE launch (rounds 4-5: one launch per sweep, three to five of them, and the
+// serial chain as a launch of its own behind them).
+//
+// One wavefront per 64 consecutive runs (lane = run), alive for all `sweeps` sweeps.  Inside the
+// chunk the system is solved exactly, run by run (forward substitution: run t's value is broadcast,
+// the later lanes whose masks name it add it to their sums -- ~20 instructions a step); what earlier
+// chunks hold comes from their PREVIOUS sweep (sweep 0: zero): the stretch of runs from the first
+// that can hold a slot of this chunk up to the chunk, staged through LDS, oldest first, every lane
+// testing the run against its own two end slots.  So sweep k is exact for every chain of
+// dependences that crosses at most k chunk boundaries, whatever its length inside a chunk (the runs
+// of the 2 cut_off + 2 windows clipped at either end of the grid form such chains: each holds the
+// end slot of all the others).  Sweeps >= 1 report a change; a sweep that changed nothing anywhere
+// has verified a fixed point, i.e. the solution a serial evaluation of the same formula gives, bit
+// for bit and independent of how it was reached.
+//
+// Between sweeps a chunk waits for exactly what it reads: progress[c'] >= k for the chunks c' of
+// its stretch -- all EARLIER chunks, which the dispatcher started before it, so the wait ends.  It is
+// bounded all the same (kSolveSpinLimit polls): a chunk whose wait runs out clears the level's
+// flag [0], everybody stops waiting, and the serial chain takes the level.  Every sweep writes a
+// buffer of its own (an earlier chunk may be a sweep ahead of a later one that still reads).
+// After its last sweep the LAST run of every bin sums the bin's pedestals (its runs in row order,
+// the earlier ones waited for like the stretch): bins without a run keep run_find_kernel's zero.
+// The chunk that leaves last (per level: an atomic count) looks at the flags and, where the
+// relaxation does not apply or has not settled, runs the serial chain itself.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHistoryTile = 256;   // earlier runs staged in LDS at a time
+constexpr int kSolveSpinLimit = 1 << 21;
+
+__device__ __forceinline__ int load_agent(const int * p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Waits until the chunks [first, last) of the level have completed `needed` sweeps.  false: given up
+// (this wait ran out, or somebody else's did: flags[0] == 0).
+__device__ __forceinline__ bool wait_for_chunks(const int * progress, int first, int last,
+                                                int needed, int * flags, int lane)
+{
+    for (int c0 = first; c0 < last; c0 += 64)
+    {
+        const int c = c0 + lane;
+        int polls = 0;
+        while (true)
+        {
+            const int done = c < last ? load_agent(&progress[c]) : needed;
+            if (__ballot(done < needed) == 0ull) break;
+            if (++polls > kSolveSpinLimit || load_agent(&flags[0]) == 0)
+            {
+                if (lane == 0) atomicAnd(&flags[0], 0);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __threadfence();        // what those chunks wrote before they raised their count is visible
+    return true;
+}
+
+template <bool WINDOW>
+__global__ __launch_bounds__(64) void run_solve_kernel(const int * __restrict__ run_count,
+                                                       int max_runs, int max_chunks, int n_bins,
+                                                       int sweeps,
+                                                       const RunLink * __restrict__ links,
+                                                       const int2 * __restrict__ run_slots,
+                                                       const int * __restrict__ run_bin,
+                                                       const int * __restrict__ bin_end,
+                                                       const int * __restrict__ bin_first,
+                                                       double * __restrict__ pedestals,
+                                                       long long sweep_stride,
+                                                       int * __restrict__ progress,
+                                                       int * __restrict__ state,
+                                                       double * __restrict__ bin_sum,
+                                                       // the serial chain's own arguments
+                                                       int slot_stride, GridSpec g, int n_cells,
+                                                       const RunMeta * __restrict__ runs,
+                                                       const double * __restrict__ slot_sums,
+                                                       double * __restrict__ global_slots)
+{
+    extern __shared__ double chain_lds[];
+    __shared__ double history_p[kHistoryTile];
+    __shared__ int2 history_slots[kHistoryTile];
+    __shared__ double own_p[64];
+    const int level = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int count = run_count[level];
+    const int base = chunk*64;
+    int * flags = state + level*kChainState;
+    int * done = progress + (long long)level*max_chunks;
+    const int chunks = (count + 63) >> 6;       // chunks of this level that hold a run
+    if (base < count && load_agent(&flags[0]) != 0)
+    {
+        const int2 * slots_of = run_slots + (long long)level*max_runs;
+        const int r = base + lane;
+        const bool valid = r < count;
+        RunLink mine;
+        mine.ks = mine.ke = 0.;
+        mine.in_s = mine.in_e = 0ull;
+        mine.bin = -1; mine.n_slots = 0; mine.begin = base; mine.first_of_bin = 0;
+        int2 ends = make_int2(-1, -1);
+        if (valid)
+        {
+            mine = links[(long long)level*max_runs + r];
+            ends = slots_of[r];
+        }
+        // The earliest run any lane of the chunk looks back to.
+        int oldest = min(mine.begin, base);
+        for (int offset = 32; offset > 0; offset >>= 1)
+        {
+            oldest = min(oldest, __shfl_xor(oldest, offset, 64));
+        }
+        const int last = min(64, count - base);
+        bool waiting = true;
+        double p = 0., given = 0.;
+        for (int sweep = 0; sweep < sweeps && waiting; ++sweep)
+        {
+            const double * from = pedestals + (sweep > 0 ? sweep - 1 : 0)*sweep_stride +
+                                  (long long)level*max_runs;
+            double * to = pedestals + sweep*sweep_stride + (long long)level*max_runs;
+            double before_s = 0., before_e = 0.;
+            given = p;          // this lane's value of the sweep before
+            if (sweep > 0 && base > 0)
+            {
+                waiting = wait_for_chunks(done, oldest >> 6, chunk, sweep, flags, lane);
+                if (!waiting) break;
+                for (int tile = oldest; tile < base; tile += kHistoryTile)
+                {
+                    const int length = min(kHistoryTile, base - tile);
+                    __builtin_amdgcn_wave_barrier();        // the previous tile has been read
+                    for (int t = lane; t < length; t += 64)
+                    {
+                        history_p[t] = from[tile + t];
+                        history_slots[t] = slots_of[tile + t];
+                    }
+                    __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
+                    for (int t = 0; t < length; ++t)
+                    {
+                        const double value = history_p[t];
+                        const int2 window = history_slots[t];
+                        if (window.x <= ends.x && ends.x <= window.y) before_s += value;
+                        if (window.x <= ends.y && ends.y <= window.y) before_e += value;
+                    }
+                }
+            }
+            // The chunk itself: run t of the chunk is bit lane-1-t of the later lanes' masks.
+            p = 0.;
+            for (int t = 0; t < last; ++t)
+            {
+                const double candidate = run_pedestal(mine.ks - before_s, mine.ke - before_e,
+                                                      mine.n_slots);
+                const double settled = read_lane(candidate, t);
+                if (lane == t) p = candidate;
+                const int j = lane - 1 - t;
+                if (j >= 0)
+                {
+                    if ((mine.in_s >> j) & 1ull) before_s += settled;
+                    if ((mine.in_e >> j) & 1ull) before_e += settled;
+                }
+            }
+            if (valid) to[r] = p;
+            if (sweep == 0 && valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins &&
+                bin_end[(long long)level*n_bins + mine.bin] - r > kMaxStretch)
+            {
+                atomicAnd(&flags[0], 0);
+            }
+            if (sweep > 0)
+            {
+                const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
+                if (__ballot(moved) != 0ull && lane == 0) atomicOr(&flags[sweep], 1);
+            }
+            __threadfence();        // this sweep's values (and flags) before the count that says so
+            if (lane == 0) __hip_atomic_store(&done[chunk], sweep + 1, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (waiting && sweeps > 0)
+        {
+            // The bins whose last run lies in this chunk: their totals of the last sweep's values,
+            // runs in row order from the bin's first (same order of additions as rounds 4-5).
+            const double * final_p = pedestals + (sweeps - 1)*sweep_stride + (long long)level*max_runs;
+            const int * bins = run_bin + (long long)level*max_runs;
+            own_p[lane] = p;
+            const bool closes = valid && mine.bin >= 0 && mine.bin < n_bins &&
+                                bin_end[(long long)level*n_bins + mine.bin] == r + 1;
+            const int first = closes ? bin_first[(long long)level*n_bins + mine.bin] : r;
+            int earliest = min(first, base);
+            for (int offset = 32; offset > 0; offset >>= 1)
+            {
+                earliest = min(earliest, __shfl_xor(earliest, offset, 64));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (load_agent(&flags[0]) != 0 &&
+                (earliest >= base || wait_for_chunks(done, earliest >> 6, chunk, sweeps, flags, lane)))
+            {
+                if (closes)
+                {
+                    double total = 0.;
+                    for (int q = first; q <= r; ++q)
+                    {
+                        if (bins[q] == mine.bin) total += q >= base ? own_p[q - base] : final_p[q];
+                    }
+                    bin_sum[(long long)level*n_bins + mine.bin] = total;
+                }
+            }
+        }
+    }
+    // Whoever leaves last looks at the flags (every chunk's are in by then) and, where the sweeps
+    // did not apply or have not settled, runs the serial chain for the level.
+    __threadfence();
+    int left = 0;
+    if (lane == 0) left = atomicAdd(&flags[kStateFinished], 1);
+    left = __builtin_amdgcn_readfirstlane(left);
+    if (left != (int)gridDim.x - 1) return;
+    __threadfence();
+    bool settled = load_agent(&flags[0]) != 0;
+    if (settled)
+    {
+        settled = false;
+        for (int k = 1; k < sweeps; ++k)
+        {
+            if (load_agent(&flags[k]) == 0) settled = true;
+        }
+    }
+    if (settled || count == 0) return;
+    // (bin totals some chunks may have written from unsettled values: the chain starts from zero)
+    for (int s = lane; s < n_bins; s += 64) bin_sum[(long long)level*n_bins + s] = 0.;
+    __syncthreads();
+    run_chain<false, WINDOW>(level, run_count, max_runs, slot_stride, g, n_cells, n_bins, runs,
+                             slot_sums, global_slots, bin_sum, chain_lds);
 }
 
 }  // namespace lbl

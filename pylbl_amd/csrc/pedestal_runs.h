@@ -20,102 +20,210 @@ __device__ __forceinline__ double read_lane(double value, int lane)
 // run is one wavefront's work in run_sums_kernel, row after row, and the recurrence holds for any
 // grouping of same-window rows, so thousands of lines in one window (a 4 M-line table has 8 000 to
 // the wavenumber at a band centre: 2.5 ms for that one wavefront) become several runs side by side.
+// `centre` receives the row's shifted line centre (its window's bin follows from it).
 __device__ __forceinline__ int opens_run(const LineWing * __restrict__ wing,
                                          const int * __restrict__ sorted_of_row,
-                                         long long r, long long n_lines)
+                                         long long r, long long n_lines, double & centre)
 {
+    centre = 0.;
     if (r >= n_lines) return 0;
     const LineWing w = wing[sorted_of_row[r]];
+    centre = w.centre;
     if (w.first > w.last) return 0;
     if (r % kRunCut == 0) return 1;
     const LineWing p = wing[sorted_of_row[r - 1]];
     return (p.first == w.first && p.last == w.last) ? 0 : 1;
 }
 
-__device__ __forceinline__ int block_inclusive_scan(int value, int * wave_total, int & block_total)
+// The run-finding kernel uses 256-thread workgroups with a handful of registers so that it can be
+// placed beside a resident accumulate grid (which leaves ~56 VGPRs and two wave slots per SIMD
+// free); 1024-thread workgroups had to wait for it to drain.
+constexpr int kScanThreads = 256;
+
+// Inclusive scan over the workgroup of (sum of `value`, maximum of `top`), both at once.
+__device__ __forceinline__ void block_scan_sum_max(int & value, int & top, int (*wave_part)[2],
+                                                   int & block_sum, int & block_top)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    int scan = value;
     for (int offset = 1; offset < 64; offset <<= 1)
     {
-        const int up = __shfl_up(scan, offset, 64);
-        if (lane >= offset) scan += up;
+        const int up_value = __shfl_up(value, offset, 64);
+        const int up_top = __shfl_up(top, offset, 64);
+        if (lane >= offset)
+        {
+            value += up_value;
+            top = max(top, up_top);
+        }
     }
-    if (lane == 63) wave_total[wave] = scan;
+    if (lane == 63)
+    {
+        wave_part[wave][0] = value;
+        wave_part[wave][1] = top;
+    }
     __syncthreads();
-    int before = 0;
-    block_total = 0;
+    int before = 0, before_top = -1;
+    block_sum = 0;
+    block_top = -1;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i)
     {
-        if (i < wave) before += wave_total[i];
-        block_total += wave_total[i];
+        if (i < wave)
+        {
+            before += wave_part[i][0];
+            before_top = max(before_top, wave_part[i][1]);
+        }
+        block_sum += wave_part[i][0];
+        block_top = max(block_top, wave_part[i][1]);
     }
     __syncthreads();
-    return before + scan;
+    value += before;
+    top = max(top, before_top);
 }
 
-// The three run-finding kernels use 256-thread workgroups with a handful of registers so that
-// they can be placed beside a resident accumulate grid (which leaves ~56 VGPRs and two wave
-// slots per SIMD free); 1024-thread workgroups had to wait for it to drain.
-constexpr int kScanThreads = 256;
+// ---------------------------------------------------------------------------------------------
+// The runs of every level in ONE launch (rounds 1-5: count / offset / compact, three launches, and a
+// fourth for the prefix maxima of the runs' bins): a single-pass scan over the blocks of
+// kScanThreads rows with decoupled look-back.  Every block publishes a 64-bit descriptor
+//     status (2 bits: 0 nothing yet, 1 the block's own aggregate, 2 inclusive prefix)
+//     | runs opened (31 bits) | largest bin + 1 (31 bits)
+// first with its own aggregate, then -- once its first wavefront has walked back over the
+// descriptors of the blocks before it, 64 at a time, adding aggregates until it meets an inclusive
+// prefix -- with its inclusive prefix.  A block only ever waits for blocks with a smaller index in
+// the same level, which the dispatcher started before it, so the wait ends; it is bounded all the
+// same (kScanSpinLimit polls, ~1 s): a block that gives up publishes a poisoned count, which every
+// later block inherits, and the host reads a run count it refuses (pedestal_finish).  Two
+// descriptor arrays take turns: a launch works in one and clears the other for the next launch on
+// this workspace (launches on one stream do not overlap).
+// The kernel also resets what the later kernels of the pass fill: the level's chain state, and
+// bin_end / bin_first / bin_sum (bins without a run keep zero).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kScanAggregate = 1ull, kScanInclusive = 2ull;
+constexpr int kScanPoison = 0x40000000;
+constexpr int kScanSpinLimit = 1 << 22;
 
-// Pass 1: runs opened inside every block of kScanThreads rows.
-__global__ __launch_bounds__(kScanThreads) void run_count_kernel(const LineWing * __restrict__ wing,
-                                                         const int * __restrict__ sorted_of_row,
-                                                         long long n_lines, int n_blocks,
-                                                         int * __restrict__ block_count)
+__device__ __forceinline__ unsigned long long scan_word(unsigned long long status, int count,
+                                                        int top)
 {
-    __shared__ int wave_total[16];
-    const int level = blockIdx.y;
-    const long long r = (long long)blockIdx.x*kScanThreads + threadIdx.x;
-    const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
-    int total;
-    block_inclusive_scan(flag, wave_total, total);
-    if (threadIdx.x == 0) block_count[(long long)level*n_blocks + blockIdx.x] = total;
+    return (status << 62) | ((unsigned long long)(unsigned)min(count, kScanPoison) << 31) |
+           (unsigned long long)(unsigned)(top + 1);
 }
 
-// Pass 2 (one block per level): exclusive scan of the block counts, in place.
-__global__ __launch_bounds__(kScanThreads) void run_offset_kernel(int n_blocks, int * __restrict__ block_count,
-                                                          int * __restrict__ run_count)
+__device__ __forceinline__ int scan_count(unsigned long long word)
 {
-    __shared__ int wave_total[16];
-    __shared__ int carry;
-    int * counts = block_count + (long long)blockIdx.x*n_blocks;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += kScanThreads)
+    return (int)((word >> 31) & 0x7fffffffull);
+}
+
+__device__ __forceinline__ int scan_top(unsigned long long word)
+{
+    return (int)(word & 0x7fffffffull) - 1;
+}
+
+__device__ __forceinline__ unsigned long long load_agent(const unsigned long long * p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_agent(unsigned long long * p, unsigned long long value)
+{
+    __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kChainState = 16;     // ints of chain state per level, see pedestal_chain.h
+
+__global__ __launch_bounds__(kScanThreads) void run_find_kernel(
+    const LineWing * __restrict__ wing, const int * __restrict__ sorted_of_row, long long n_lines,
+    int n_blocks, int bin_origin, unsigned long long * __restrict__ scan_now,
+    unsigned long long * __restrict__ scan_next, long long scan_capacity,
+    int * __restrict__ run_start, int * __restrict__ prefix_bin, int * __restrict__ run_count,
+    int n_bins, int * __restrict__ bin_end, int * __restrict__ bin_first,
+    double * __restrict__ bin_sum, int * __restrict__ state, int start_state)
+{
+    __shared__ int wave_part[kScanThreads/64][2];
+    __shared__ int before[2];
+    const int level = blockIdx.y, block = blockIdx.x;
+    // Housekeeping for the rest of the pass and for the next launch.
     {
-        const int i = base + threadIdx.x;
-        const int value = i < n_blocks ? counts[i] : 0;
-        int total;
-        const int inclusive = block_inclusive_scan(value, wave_total, total);
-        const int before = carry;
-        if (i < n_blocks) counts[i] = before + inclusive - value;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = before + total;
-        __syncthreads();
+        const long long threads = (long long)gridDim.x*gridDim.y*kScanThreads;
+        const long long me = ((long long)level*n_blocks + block)*kScanThreads + threadIdx.x;
+        for (long long i = me; i < scan_capacity; i += threads) scan_next[i] = 0ull;
+        for (int i = block*kScanThreads + threadIdx.x; i < n_bins; i += n_blocks*kScanThreads)
+        {
+            bin_end[(long long)level*n_bins + i] = 0;
+            bin_first[(long long)level*n_bins + i] = 0x7fffffff;
+            bin_sum[(long long)level*n_bins + i] = 0.;
+        }
+        if (block == 0 && threadIdx.x < kChainState)
+        {
+            state[level*kChainState + threadIdx.x] = threadIdx.x == 0 ? start_state : 0;
+        }
     }
-    if (threadIdx.x == 0) run_count[blockIdx.x] = carry;
-}
-
-// Pass 3: rows that open a run, compacted in row order.
-__global__ __launch_bounds__(kScanThreads) void run_compact_kernel(const LineWing * __restrict__ wing,
-                                                           const int * __restrict__ sorted_of_row,
-                                                           long long n_lines, int n_blocks,
-                                                           const int * __restrict__ block_offset,
-                                                           int * __restrict__ run_start)
-{
-    __shared__ int wave_total[16];
-    const int level = blockIdx.y;
-    const long long r = (long long)blockIdx.x*kScanThreads + threadIdx.x;
-    const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines);
-    int total;
-    const int inclusive = block_inclusive_scan(flag, wave_total, total);
-    if (flag)
+    const long long r = (long long)block*kScanThreads + threadIdx.x;
+    double centre;
+    const int flag = opens_run(wing + (long long)level*n_lines, sorted_of_row, r, n_lines, centre);
+    // (the run's bin as run_sums_kernel forms it, RunMeta::bin, kept inside what a descriptor holds)
+    const int bin = flag ? min(max((int)floor(centre) - bin_origin, -1), kScanPoison) : -1;
+    int inclusive = flag, top = bin, total, block_top;
+    block_scan_sum_max(inclusive, top, wave_part, total, block_top);
+    if (threadIdx.x < 64)
     {
-        const int at = block_offset[(long long)level*n_blocks + blockIdx.x] + inclusive - 1;
+        const int lane = threadIdx.x;
+        unsigned long long * descriptors = scan_now + (long long)level*n_blocks;
+        int count_before = 0, top_before = -1;
+        if (block > 0)
+        {
+            if (lane == 0) store_agent(&descriptors[block], scan_word(kScanAggregate, total, block_top));
+            bool gave_up = false;
+            for (int base = block - 1; base >= 0; base -= 64)
+            {
+                const int at = base - lane;
+                unsigned long long word = 0ull;
+                int polls = 0;
+                while (true)
+                {
+                    word = at >= 0 ? load_agent(&descriptors[at]) : (kScanAggregate << 62) | 0ull;
+                    if (__ballot((word >> 62) == 0ull) == 0ull) break;
+                    if (++polls > kScanSpinLimit)
+                    {
+                        gave_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (gave_up) break;
+                const unsigned long long closed = __ballot(at >= 0 && (word >> 62) == kScanInclusive);
+                const int stop = closed != 0ull ? __builtin_ctzll(closed) : 63;
+                const bool take = at >= 0 && lane <= stop;
+                int count = take ? scan_count(word) : 0;
+                int best = take ? scan_top(word) : -1;
+                for (int offset = 32; offset > 0; offset >>= 1)
+                {
+                    count = min(count + __shfl_xor(count, offset, 64), kScanPoison);
+                    best = max(best, __shfl_xor(best, offset, 64));
+                }
+                count_before = min(count_before + count, kScanPoison);
+                top_before = max(top_before, best);
+                if (closed != 0ull) break;
+            }
+            if (gave_up) count_before = kScanPoison;
+        }
+        if (lane == 0)
+        {
+            store_agent(&descriptors[block],
+                        scan_word(kScanInclusive, count_before + total, max(top_before, block_top)));
+            before[0] = count_before;
+            before[1] = top_before;
+        }
+    }
+    __syncthreads();
+    const long long at = (long long)before[0] + inclusive - 1;
+    if (flag && at < n_lines)
+    {
         run_start[(long long)level*n_lines + at] = (int)r;
+        prefix_bin[(long long)level*n_lines + at] = max(before[1], top);
+    }
+    if (block == n_blocks - 1 && threadIdx.x == 0)
+    {
+        run_count[level] = min(before[0] + total, kScanPoison);
     }
 }
 
