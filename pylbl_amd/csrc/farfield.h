@@ -43,7 +43,7 @@ namespace lbl {
 //                           so nothing is truncated twice);
 // and the accumulate kernel evaluates one polynomial per point as before.  Reads and arithmetic
 // drop ~2.9x for kFarGroup = 4.
-constexpr int kFarGroup = 4;
+constexpr int kFarGroup = 4;       // = wavefronts per workgroup of farfield_series_kernel
 // First index in [lo, hi] whose wavenumber is > x (ABOVE) or >= x, found by a whole wavefront: 64
 // probes per step, so ~3400 candidates take two loads' latency where a binary search takes
 // twelve (the search is the serial head of its workgroup).
@@ -85,16 +85,12 @@ __device__ __forceinline__ void group_bounds(const Tiling & tiling, int group, i
     tile_bounds(tiling, t1, n_per_v, n, unused, i1);
 }
 
-// Series of the lines [begin, end) of a list (index ranges laid end to end by `line_at`) about u0,
-// summed over the workgroup in a fixed order; thread k < kFarTerms returns term k (the others 0).
-template <typename LineAt>
-__device__ __forceinline__ double series_of_lines(const LineWing * __restrict__ w, int begin,
-                                                  int end, LineAt line_at, double u0,
-                                                  double (&wave_sum)[4][kFarTerms])
+// Series about u0 of every THREADS-th line of a list (index ranges laid end to end by `line_at`),
+// from `first` up to `end`, added term by term into c.
+template <int THREADS, typename LineAt>
+__device__ __forceinline__ void series_terms(const LineWing * __restrict__ w, int first, int end,
+                                             LineAt line_at, double u0, double (&c)[kFarTerms])
 {
-    double c[kFarTerms];
-#pragma unroll
-    for (int k = 0; k < kFarTerms; ++k) c[k] = 0.;
     auto add_line = [&](const LineWing & l) {
         const double a = l.centre - u0;
         const double r = rcp_newton(__builtin_fma(a, a, l.g2));
@@ -112,11 +108,11 @@ __device__ __forceinline__ double series_of_lines(const LineWing * __restrict__ 
             q1 = q2;
         }
     };
-    int at = begin + (int)threadIdx.x;
-    for (; at + 256 < end; at += 512)       // two loads in flight
+    int at = first;
+    for (; at + THREADS < end; at += 2*THREADS)     // two loads in flight
     {
         const LineWing l0 = w[line_at(at)];
-        const LineWing l1 = w[line_at(at + 256)];
+        const LineWing l1 = w[line_at(at + THREADS)];
         add_line(l0);
         add_line(l1);
     }
@@ -124,30 +120,15 @@ __device__ __forceinline__ double series_of_lines(const LineWing * __restrict__ 
     {
         add_line(w[line_at(at)]);
     }
-    // Sum over the 64 lanes (wave_ops.h: 21 butterflies through the LDS crossbar were most of
-    // this kernel's time), then over the 4 wavefronts: fixed order.
-    const int wave = threadIdx.x >> 6;
-    int index;
-    bool valid;
-    wave_sums(c, index, valid);
-    if (valid) wave_sum[wave][index] = c[0];
-    __syncthreads();
-    double term = 0.;
-    if (threadIdx.x < kFarTerms)
-    {
-        const int k = threadIdx.x;
-        term = (wave_sum[0][k] + wave_sum[1][k]) + (wave_sum[2][k] + wave_sum[3][k]);
-    }
-    return term;
 }
 
-// One 256-thread workgroup per (group of kFarGroup tiles, level): first the series of the group's
-// very far lines about the group's centre (into LDS), then, tile by tile, what only the tile can
-// take -- the lines between the tile's own limit and the group's, and the few whose windows cover
-// this tile but not the whole group -- plus the group's polynomial re-centred on the tile.
-// (Rounds 3-5 ran the two steps as two launches, farfield_group_kernel and farfield_kernel, with
-// the group's cuts and series going through HBM in between; the sums are formed by the same
-// threads in the same order, so the coefficients are the same bits.)
+// One 256-thread workgroup per (group of kFarGroup = 4 tiles, level): first the series of the
+// group's very far lines about the group's centre (all four wavefronts, into LDS), then every
+// wavefront takes one tile of the group -- the lines between the tile's own limit and the group's,
+// and the few whose windows cover this tile but not the whole group -- and adds the group's
+// polynomial re-centred on its tile.  (Rounds 3-5 ran the two steps as two launches,
+// farfield_group_kernel and farfield_kernel, with the group's cuts and series going through HBM in
+// between, and a whole workgroup per tile.)
 __global__ __launch_bounds__(256) void farfield_series_kernel(
     const LineWing * __restrict__ wing, const TileSchedule * __restrict__ schedule,
     const double * __restrict__ nu, const LevelScalars * __restrict__ levels, long long n_lines,
@@ -224,80 +205,74 @@ __global__ __launch_bounds__(256) void farfield_series_kernel(
     gc.g2 = __builtin_amdgcn_readfirstlane(shared_cuts.g2);
     gc.a2 = __builtin_amdgcn_readfirstlane(shared_cuts.a2);
     const LineWing * __restrict__ w = wing + (long long)level*n_lines;
-    // Job 0: the group's own series, about the group's centre; jobs 1 .. : the tiles of the group,
-    // each about its own centre.  One call site of series_of_lines for all of them (two of them
-    // cost the kernel twice the registers): a job is up to four index ranges laid end to end.
-#pragma unroll 1
-    for (int job = 0; job <= t1 - t0; ++job)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // The group's own series about the group's centre: all 256 threads, summed over the 64 lanes
+    // (wave_ops.h: 21 butterflies through the LDS crossbar were most of this kernel's time), then
+    // over the 4 wavefronts, in a fixed order.
     {
-        int begin0, begin1, begin2, begin3, n0, n1, n2, n3;
-        double u0;
-        if (job == 0)
-        {
-            begin0 = gc.a1; n0 = max(gc.g1 - gc.a1, 0);
-            begin1 = gc.g2; n1 = max(gc.a2 - gc.g2, 0);
-            begin2 = begin3 = 0; n2 = n3 = 0;
-            u0 = group_centre;
-        }
-        else
-        {
-            const int tile = t0 + job - 1;
-            const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
-            long long q0, q1;
-            tile_bounds(tiling, tile, n_per_v, n, q0, q1);
-            u0 = tile_centre(v0, dv, q0, q1);
-            // This tile's far lines [a1, f1) and [f2, a2) without the group's [gc.a1, gc.g1),
-            // [gc.g2, gc.a2): four pieces laid end to end.
-            const int l1 = min(max(gc.a1, sc.a1), sc.f1);       // [a1, l1): cover this tile, not the group
-            const int l2 = min(max(gc.g1, l1), sc.f1);          // [l2, f1): nearer than the group's limit
-            const int r2 = max(min(gc.a2, sc.a2), sc.f2);       // [r2, a2)
-            const int r1 = max(min(gc.g2, r2), sc.f2);          // [f2, r1)
-            begin0 = sc.a1; n0 = l1 - sc.a1;
-            begin1 = l2; n1 = sc.f1 - l2;
-            begin2 = sc.f2; n2 = r1 - sc.f2;
-            begin3 = r2; n3 = sc.a2 - r2;
-        }
-        const double own = series_of_lines(
-            w, 0, n0 + n1 + n2 + n3,
-            [&](int at) {
-                if (at < n0) return begin0 + at;
-                at -= n0;
-                if (at < n1) return begin1 + at;
-                at -= n1;
-                if (at < n2) return begin2 + at;
-                return begin3 + (at - n2);
-            }, u0, wave_sum);
+        const int left = max(gc.g1 - gc.a1, 0);
+        const int total = left + max(gc.a2 - gc.g2, 0);
+        double c[kFarTerms];
+#pragma unroll
+        for (int k = 0; k < kFarTerms; ++k) c[k] = 0.;
+        series_terms<256>(w, (int)threadIdx.x, total,
+                          [&](int at) { return at < left ? gc.a1 + at : gc.g2 + (at - left); },
+                          group_centre, c);
+        int index;
+        bool valid;
+        wave_sums(c, index, valid);
+        if (valid) wave_sum[wave][index] = c[0];
+        __syncthreads();
         if (threadIdx.x < kFarTerms)
         {
-            const int j = threadIdx.x;
-            if (job == 0)
-            {
-                group_term[j] = own;
-            }
-            else
-            {
-                // The group's polynomial in w = u + d about this tile's centre.
-                const double d = u0 - group_centre;
-                double shifted = 0., weight = 1.;       // weight = C(j+m, j) d^m
-                // (the binomial factors depend on the thread alone: hidden from the optimiser, which
-                // would otherwise keep all 21 of them in registers around the loop over the jobs --
-                // 130 VGPRs instead of 70)
-                int row = j;
-                asm volatile("" : "+v"(row));
-#pragma unroll
-                for (int m = 0; m < kFarTerms; ++m)
-                {
-                    if (j + m < kFarTerms)
-                    {
-                        shifted = __builtin_fma(group_term[j + m], weight, shifted);
-                        weight *= d*((double)(row + m + 1)*(1./(double)(m + 1)));
-                    }
-                }
-                far_series[((long long)level*tiling.n_tiles + t0 + job - 1)*kFarTerms + j] =
-                    own + shifted;
-            }
+            const int k = threadIdx.x;
+            group_term[k] = (wave_sum[0][k] + wave_sum[1][k]) + (wave_sum[2][k] + wave_sum[3][k]);
         }
-        __syncthreads();    // group_term is complete / wave_sum has been read
+        __syncthreads();
+    }
+    // The tiles of the group, one per wavefront, side by side: each about its own centre, what only
+    // the tile can take, plus the group's polynomial re-centred on it.
+    static_assert(kFarGroup == 4, "one tile of the group per wavefront");
+    const int tile = t0 + wave;
+    if (tile >= t1) return;
+    const TileSchedule sc = schedule[(long long)level*tiling.n_tiles + tile];
+    long long q0, q1;
+    tile_bounds(tiling, tile, n_per_v, n, q0, q1);
+    const double u0 = tile_centre(v0, dv, q0, q1);
+    // This tile's far lines [a1, f1) and [f2, a2) without the group's [gc.a1, gc.g1),
+    // [gc.g2, gc.a2): four pieces laid end to end.
+    const int l1 = min(max(gc.a1, sc.a1), sc.f1);       // [a1, l1): cover this tile, not the group
+    const int l2 = min(max(gc.g1, l1), sc.f1);          // [l2, f1): nearer than the group's limit
+    const int r2 = max(min(gc.a2, sc.a2), sc.f2);       // [r2, a2)
+    const int r1 = max(min(gc.g2, r2), sc.f2);          // [f2, r1)
+    const int n0 = l1 - sc.a1, n1 = sc.f1 - l2, n2 = r1 - sc.f2, n3 = sc.a2 - r2;
+    double c[kFarTerms];
+#pragma unroll
+    for (int k = 0; k < kFarTerms; ++k) c[k] = 0.;
+    series_terms<64>(w, lane, n0 + n1 + n2 + n3,
+                     [&](int at) {
+                         if (at < n0) return sc.a1 + at;
+                         at -= n0;
+                         if (at < n1) return l2 + at;
+                         at -= n1;
+                         if (at < n2) return sc.f2 + at;
+                         return r2 + (at - n2);
+                     }, u0, c);
+    int j;
+    bool valid;
+    wave_sums(c, j, valid);
+    if (valid)
+    {
+        // Lane `lane` holds term j of the tile's own series; the group's polynomial in
+        // w = u + d about this tile's centre (a Taylor shift) is added to it.
+        const double d = u0 - group_centre;
+        double shifted = 0., weight = 1.;       // weight = C(j+m, j) d^m
+        for (int m = 0; j + m < kFarTerms; ++m)
+        {
+            shifted = __builtin_fma(group_term[j + m], weight, shifted);
+            weight *= d*((double)(j + m + 1)*rcp_newton((double)(m + 1)));
+        }
+        far_series[((long long)level*tiling.n_tiles + tile)*kFarTerms + j] = c[0] + shifted;
     }
 }
 
