@@ -183,6 +183,15 @@ class Pending(object):
         self.seconds = None
         self.result = None
         self.done = False
+        # Device tensors: an event behind everything the stream that issued the exchange has been
+        # given so far (staging copies, the rank's own blocks placed in the collected array).  A
+        # later writer of the buffers waits for it too: the work objects only stand for the
+        # transfer, and the caller may by then be under another torch stream.
+        self.issued = None
+        if device is not None:
+            import torch
+            self.issued = torch.cuda.Event()
+            self.issued.record(torch.cuda.current_stream(device))
 
     def _late(self, timeout):
         return ExchangeTimeout(
@@ -224,6 +233,8 @@ class Pending(object):
             # collected array on that stream, and the engine overwrites them two calls later.)
             stream = torch.cuda.current_stream(self.device)
             with torch.cuda.device(self.device):
+                if self.issued is not None:
+                    stream.wait_event(self.issued)
                 for request in self.requests:
                     request.wait()
                 marker = torch.cuda.Event()
@@ -384,7 +395,8 @@ class ShardedLines(object):
     def _settle(self, key, writer):
         """Orders the next writer of buffer `key` behind the exchange that last read or wrote it
         (if that is still in flight).  Host tensors: the host waits for the exchange (gloo's
-        requests complete inside wait() only).  Device tensors: the exchange library's current
+        requests complete inside wait() only: this may block for up to PYLBL_AMD_EXCHANGE_TIMEOUT
+        seconds and raise ExchangeTimeout).  Device tensors: the exchange library's current
         stream waits for the exchange's work objects -- no host wait -- and, when the writer is
         `compute`, the engine's streams are then ordered behind that stream."""
         pending = self._users.pop(key, None)
@@ -395,6 +407,10 @@ class ShardedLines(object):
             return
         import torch
         with torch.cuda.device(pending.device):
+            if pending.issued is not None:
+                # (what the issuing stream did around the exchange, should the caller have changed
+                # torch streams since)
+                torch.cuda.current_stream(pending.device).wait_event(pending.issued)
             for request in pending.requests:
                 request.wait()              # nccl: orders torch's current stream, not the host
         if writer == "compute":

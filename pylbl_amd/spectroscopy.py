@@ -433,7 +433,12 @@ class Spectroscopy(object):
                         # slot kernels then wait for the first gas's pedestal to be applied and the
                         # heaviest gas is queued later, 1.58 -> 1.70 ms.)
                         # (every continuum of every gas in ONE pass -- the block is written once --
-                        # then the cross-sections)
+                        # then the cross-sections.  The additions into the block therefore run
+                        # c(g1), c(g2), ..., x(g1), x(g2), ..., lines -- not the reference's
+                        # gas-by-gas order, spectroscopy.py:225-234: the continua are bit-identical
+                        # to the one-by-one sum among themselves, the total may differ from the
+                        # reference's order of additions in its last bits, within the parity bar:
+                        # tests/test_gpu_api.py::test_total_with_continuum_and_cross_section_of_two_gases)
                         continua_into([c for _, _, continua_here, _ in present
                                        for c in continua_here], total)
                         for name, gas, continua_here, cross in present:

@@ -170,6 +170,48 @@ def test_spectroscopy_cross_section_slot(tmp_path):
         Spectroscopy(atmos, grid, None, cross_sections_backend="not-a-model")
 
 
+def test_total_with_continuum_and_cross_section_of_two_gases(tmp_path, monkeypatch):
+    """Output "total" queues every continuum of every gas in one pass, then the cross-sections,
+    then the lines (Spectroscopy.compute_absorption): c(g1), c(g2), x(g1), x(g2), lines -- where the
+    reference adds gas by gas, mechanism by mechanism (spectroscopy.py:225-234).  Two gases with
+    lines, an MT-CKD continuum AND a cross-section each: the total equals the sum of the "all"
+    output taken in the reference's order to rounding (1e-12 of the largest value)."""
+    import os
+    from pylbl_amd import Spectroscopy
+    from pylbl_amd.database import Database, write_database
+    fixture = os.path.join(os.path.dirname(__file__), "golden", "mt_ckd_bands.npz")
+    monkeypatch.setenv("PYLBL_MT_CKD", fixture)
+    atmos = synthetic.fixture_atmosphere()
+    files = {}
+    for i, formula in enumerate(("CO2", "O3")):
+        bands = synthetic.cross_section_bands(seed=21 + i, ranges=((30. + 20*i, 70. + 20*i),),
+                                              spacing=0.02)
+        files[formula] = str(tmp_path / f"{formula}.npz")
+        arts_crossfit.write_npz(files[formula], bands)
+    # (every gas of the atmosphere is in the database, as in the reference's fixture; only CO2 and
+    # O3 have partition sums, i.e. lines)
+    tables = [synthetic.line_table(formula, 1., 130., num_lines=300 if formula in files else 5,
+                                   seed=71 + i, tips_range=(150, 400))
+              for i, formula in enumerate(atmos.vmr)]
+    path = tmp_path / "lines.db"
+    write_database(path, tables, with_tips=set(files), cross_sections=files)
+    level = atmos
+    grid = np.arange(1., 120., 0.05)
+    spec = Spectroscopy(level, grid, Database(str(path)))
+    everything = spec.compute_absorption(output_format="all")
+    total = np.asarray(spec.compute_absorption(output_format="total")["absorption"])
+    in_reference_order = np.zeros_like(total)
+    for formula in level.vmr:                   # (H2O, O2 and N2 ride along with their continua)
+        if f"{formula}_absorption" not in everything:
+            continue
+        beta = np.asarray(everything[f"{formula}_absorption"])
+        if formula in ("CO2", "O3"):
+            assert beta[:, 0].any() and beta[:, 1].any() and beta[:, 2].any(), formula
+        for mechanism in range(3):
+            in_reference_order += beta[:, mechanism]
+    assert np.max(np.abs(total - in_reference_order)) <= 1e-12*np.max(in_reference_order)
+
+
 def test_coefficient_file_in_the_reference_layout():
     """The netCDF-4 file of tests/golden (layout of cross_section.py:29-41) through
     CrossSection on the GPU against what the reference's own class returned for it
