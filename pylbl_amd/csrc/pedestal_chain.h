@@ -476,6 +476,22 @@ __device__ __forceinline__ int load_agent(const int * p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A pedestal total another chunk (on any XCD, each with an L2 of its own) has written / will read
+// during this launch: device-scope accesses, coherent by themselves.  The order against the count
+// that announces them is kept by a workgroup-scope fence (the stores have completed before the
+// count is stored), not by an agent-scope one -- that would write the XCD's whole L2 back, every
+// sweep of every chunk, under the accumulate grid that is filling it (profiles/r06_ab_combine_in_kernel.txt
+// is what such fences cost).
+__device__ __forceinline__ double load_shared(const double * p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_shared(double * p, double value)
+{
+    __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Waits until the chunks [first, last) of the level have completed `needed` sweeps.  false: given up
 // (this wait ran out, or somebody else's did: flags[0] == 0).
 __device__ __forceinline__ bool wait_for_chunks(const int * progress, int first, int last,
@@ -497,7 +513,10 @@ __device__ __forceinline__ bool wait_for_chunks(const int * progress, int first,
             __builtin_amdgcn_s_sleep(2);
         }
     }
-    __threadfence();        // what those chunks wrote before they raised their count is visible
+    // (The values those chunks wrote before they raised their count are read by loads that go to
+    // the device's coherence point themselves -- load_shared below --, like the counts: no cache
+    // has to be written back or invalidated for them.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
 }
 
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(64) void run_solve_kernel(const int * __restrict__ 
                     __builtin_amdgcn_wave_barrier();        // the previous tile has been read
                     for (int t = lane; t < length; t += 64)
                     {
-                        history_p[t] = from[tile + t];
+                        history_p[t] = load_shared(&from[tile + t]);
                         history_slots[t] = slots_of[tile + t];
                     }
                     __builtin_amdgcn_wave_barrier();        // one wavefront: LDS keeps program order
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(64) void run_solve_kernel(const int * __restrict__ 
                     if ((mine.in_e >> j) & 1ull) before_e += settled;
                 }
             }
-            if (valid) to[r] = p;
+            if (valid) store_shared(&to[r], p);
             if (sweep == 0 && valid && mine.first_of_bin && mine.bin >= 0 && mine.bin < n_bins &&
                 bin_end[(long long)level*n_bins + mine.bin] - r > kMaxStretch)
             {
@@ -613,7 +632,8 @@ __global__ __launch_bounds__(64) void run_solve_kernel(const int * __restrict__ 
                 const bool moved = valid && __double_as_longlong(p) != __double_as_longlong(given);
                 if (__ballot(moved) != 0ull && lane == 0) atomicOr(&flags[sweep], 1);
             }
-            __threadfence();        // this sweep's values (and flags) before the count that says so
+            // this sweep's values (and flags) before the count that says so
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[chunk], sweep + 1, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -641,21 +661,22 @@ __global__ __launch_bounds__(64) void run_solve_kernel(const int * __restrict__ 
                     double total = 0.;
                     for (int q = first; q <= r; ++q)
                     {
-                        if (bins[q] == mine.bin) total += q >= base ? own_p[q - base] : final_p[q];
+                        if (bins[q] == mine.bin) total += q >= base ? own_p[q - base] : load_shared(&final_p[q]);
                     }
-                    bin_sum[(long long)level*n_bins + mine.bin] = total;
+                    store_shared(&bin_sum[(long long)level*n_bins + mine.bin], total);
                 }
             }
         }
     }
-    // Whoever leaves last looks at the flags (every chunk's are in by then) and, where the sweeps
+    // Whoever leaves last looks at the flags (every chunk's are in by then: device-scope atomics,
+    // like the bin totals above, completed before the chunk counts itself out) and, where the sweeps
     // did not apply or have not settled, runs the serial chain for the level.
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int left = 0;
     if (lane == 0) left = atomicAdd(&flags[kStateFinished], 1);
     left = __builtin_amdgcn_readfirstlane(left);
     if (left != (int)gridDim.x - 1) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     bool settled = load_agent(&flags[0]) != 0;
     if (settled)
     {

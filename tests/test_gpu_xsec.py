@@ -183,13 +183,13 @@ def test_total_with_continuum_and_cross_section_of_two_gases(tmp_path, monkeypat
     monkeypatch.setenv("PYLBL_MT_CKD", fixture)
     atmos = synthetic.fixture_atmosphere()
     files = {}
-    for i, formula in enumerate(("CO2", "O3")):
+    for i, formula in enumerate(("CO2", "H2O")):
         bands = synthetic.cross_section_bands(seed=21 + i, ranges=((30. + 20*i, 70. + 20*i),),
                                               spacing=0.02)
         files[formula] = str(tmp_path / f"{formula}.npz")
         arts_crossfit.write_npz(files[formula], bands)
     # (every gas of the atmosphere is in the database, as in the reference's fixture; only CO2 and
-    # O3 have partition sums, i.e. lines)
+    # H2O have partition sums, i.e. lines)
     tables = [synthetic.line_table(formula, 1., 130., num_lines=300 if formula in files else 5,
                                    seed=71 + i, tips_range=(150, 400))
               for i, formula in enumerate(atmos.vmr)]
@@ -205,7 +205,7 @@ def test_total_with_continuum_and_cross_section_of_two_gases(tmp_path, monkeypat
         if f"{formula}_absorption" not in everything:
             continue
         beta = np.asarray(everything[f"{formula}_absorption"])
-        if formula in ("CO2", "O3"):
+        if formula in ("CO2", "H2O"):
             assert beta[:, 0].any() and beta[:, 1].any() and beta[:, 2].any(), formula
         for mechanism in range(3):
             in_reference_order += beta[:, mechanism]
