@@ -1,5 +1,6 @@
-"""Prints the results table of DESIGN.md section 8 from profiles/bench_<tag>*.json (the files
-scripts/bench_round.sh writes).  Build container: python scripts/design_numbers.py r05b"""
+"""Prints the results table of DESIGN.md section 8 from profiles/bench_<tag>*_full.json (the whole
+records scripts/bench_round.sh writes beside the short lines).  Build container:
+python scripts/design_numbers.py r06a"""
 import json
 import sys
 
@@ -7,8 +8,8 @@ tag = sys.argv[1]
 
 
 def read(name=""):
-    with open(f"profiles/bench_{tag}{'_' + name if name else ''}.json") as handle:
-        return json.loads(handle.read().strip().splitlines()[-1])
+    with open(f"profiles/bench_{tag}{'_' + name if name else ''}_full.json") as handle:
+        return json.load(handle)
 
 
 d = read()
@@ -34,15 +35,14 @@ rows = [
     ("**far-field series with the pedestal (the `Spectroscopy` default)**",
      f["remove_pedestal"]["value"], f["remove_pedestal"]["ms_per_step"],
      f["remove_pedestal"]["spectra_per_s"],
-     "plain %.3f ms (%.3g); round 4: 0.77 plain / **1.08** with the pedestal; fp64 issue slots "
+     "plain %.3f ms (%.3g); round 5: 0.705 plain / 0.778 with the pedestal; fp64 issue slots "
      "filled %.2f / %.2f" % (f["plain"]["ms_per_step"], f["plain"]["value"],
                              f["plain"]["roofline"]["frac"] or 0., f["remove_pedestal"]["roofline"]["frac"] or 0.)),
     ("configs[0]: CO2, 500–800 @ 0.1 (4 calls in flight)", d["small_grid_options"]["config0"]["value"],
      d["small_grid_options"]["config0"]["ms_per_step"], d["small_grid_options"]["config0"]["spectra_per_s"],
-     "timed line %.3g, frac %.3f (12 workgroups: launch-bound); as a replayed graph %.1f µs per call "
-     "against %.1f" % (read("config0")["value"], read("config0")["roofline"]["frac"],
-                       d["small_grid_options"]["config0"]["graph_replay_option"]["on"]["ring_us_per_call"],
-                       d["small_grid_options"]["config0"]["graph_replay_option"]["off"]["ring_us_per_call"])),
+     "timed line %.3g, frac %.3f (12 workgroups: launch-bound); %.1f µs per call in the ring" % (
+         read("config0")["value"], read("config0")["roofline"]["frac"],
+         d["small_grid_options"]["config0"]["us_per_call"])),
     ("configs[1]: H2O+CO2, 1–5000 @ 0.01 (4 calls in flight)", d["small_grid_options"]["config1"]["value"],
      d["small_grid_options"]["config1"]["ms_per_step"], d["small_grid_options"]["config1"]["spectra_per_s"],
      "timed line %.3g, frac %.2f" % (read("config1")["value"], read("config1")["roofline"]["frac"])),
@@ -79,7 +79,7 @@ out.append("| slot 2: one two-band cross-section molecule | %.3g pts/s | %.3f | 
                x["roofline"]["frac"]))
 a = d["api_call"]["formats"]
 out.append("| `Spectroscopy.compute_absorption()`, host arrays: `\"total\"` / `\"gas\"` / `\"all\"` | — | "
-           "**%.2f / %.2f / %.2f** | %.0f / %.0f / %.0f | round 4: 1.62 / 2.12 / 3.33; link fractions %.2f / "
+           "**%.2f / %.2f / %.2f** | %.0f / %.0f / %.0f | round 5: 1.48 / 2.07 / 3.69; link fractions %.2f / "
            "%.2f / %.2f of %.0f GB/s |" % (
                a["total"]["ms_per_call"], a["gas"]["ms_per_call"], a["all"]["ms_per_call"],
                a["total"]["spectra_per_s"], a["gas"]["spectra_per_s"], a["all"]["spectra_per_s"],
