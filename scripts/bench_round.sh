@@ -8,7 +8,7 @@ python bench.py --steps 20 --warmup 5 --full-record $O/bench_${TAG}_full.json > 
 echo "default done"
 python bench.py --steps 20 --warmup 5 --pedestal --no-extras --full-record $O/bench_${TAG}_pedestal_full.json > $O/bench_${TAG}_pedestal.json 2>> $O/bench_${TAG}.err || exit 1
 for c in 0 1 2; do
-  python bench.py --steps 20 --warmup 5 --config $c --no-extras --full-record $O/bench_${TAG}_config$c_full.json > $O/bench_${TAG}_config$c.json 2>> $O/bench_${TAG}.err || exit 1
+  python bench.py --steps 20 --warmup 5 --config $c --no-extras --full-record $O/bench_${TAG}_config${c}_full.json > $O/bench_${TAG}_config$c.json 2>> $O/bench_${TAG}.err || exit 1
 done
 echo "configs 0-2 done"
 python bench.py --steps 5 --warmup 2 --config 3 --levels-per-gpu 16 --profile standard --pedestal --no-extras --full-record $O/bench_${TAG}_config3_16levels_full.json > $O/bench_${TAG}_config3_16levels.json 2>> $O/bench_${TAG}.err || exit 1
