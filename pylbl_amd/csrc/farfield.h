@@ -44,32 +44,6 @@ namespace lbl {
 // and the accumulate kernel evaluates one polynomial per point as before.  Reads and arithmetic
 // drop ~2.9x for kFarGroup = 4.
 constexpr int kFarGroup = 4;       // = wavefronts per workgroup of farfield_series_kernel
-// First index in [lo, hi] whose wavenumber is > x (ABOVE) or >= x, found by a whole wavefront: 64
-// probes per step, so ~3400 candidates take two loads' latency where a binary search takes
-// twelve (the search is the serial head of its workgroup).
-template <bool ABOVE>
-__device__ inline int wave_search(const double * __restrict__ nu, int lo, int hi, double x)
-{
-    const int lane = threadIdx.x & 63;
-    while (hi - lo > 64)
-    {
-        const int stride = (hi - lo + 63) >> 6;
-        const int at = lo + lane*stride;
-        const bool below = at < hi && (ABOVE ? nu[at] <= x : nu[at] < x);
-        const int count = __builtin_popcountll(__ballot(below));
-        if (count == 0)
-        {
-            return lo;
-        }
-        const int base = lo + (count - 1)*stride;
-        hi = min(base + stride, hi);
-        lo = base + 1;
-    }
-    const int at = lo + lane;
-    const bool below = at < hi && (ABOVE ? nu[at] <= x : nu[at] < x);
-    return lo + __builtin_popcountll(__ballot(below));
-}
-
 struct GroupCuts
 {
     int a1, g1, g2, a2;     // the group's very far lines: [a1, g1) below it, [g2, a2) above it

@@ -20,10 +20,12 @@
 #include <hip/hip_runtime.h>
 
 #include "continuum.h"      // load_points / store_points
+#include "wave_ops.h"       // wave_search
 
 namespace lbl {
 
 constexpr int kMaxXsecBands = 16;
+constexpr int kXsecStage = 1024;         // frequencies of a band staged in LDS per workgroup and band
 constexpr double kSpeedOfLight = 299792458.0;       // cross_section.py:31
 constexpr double kBoltzmann = 1.38064852e-23;       // spectroscopy.py:15
 
@@ -133,6 +135,11 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
                                                           long long level_stride, int accumulate)
 {
     __shared__ int window[kMaxXsecBands][2];
+    // The frequencies of a band that this workgroup's points can fall between, staged once per
+    // band (round 6): the binary search then walks LDS, where rounds 1-5 walked HBM -- six dependent
+    // round trips per point, 77 % of the kernel's wave-cycles spent waiting
+    // (profiles/r05b_valu_counters.json).
+    __shared__ double staged[kXsecStage];
     // Points of a thread as in continuum_interp_kernel: neighbouring pairs, pairs 512 apart.
     static_assert(PT == 1 || PT % 2 == 0, "points come in pairs");
     const long long block_first = (long long)blockIdx.x*(256*PT);
@@ -142,21 +149,36 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
     };
     const int level0 = blockIdx.y*LV;
     const int count = min(LV, n_levels - level0);
-    // Search window of every band for this workgroup's points: exact when the grid ascends.
-    if ((int)threadIdx.x < set.n_bands)
+    // Search window of every band for this workgroup's points: exact when the grid ascends.  Two
+    // searches per band over its whole frequency axis -- the serial head of every workgroup: one
+    // wavefront each, 64 probes a step (wave_ops.h: two dependent loads for 1 300 frequencies where
+    // a thread's binary search took eleven), two bands at a time.
+    if (ascending)
     {
-        const XsecBand b = set.band[threadIdx.x];
-        int lo = 0, hi = b.size;
-        if (ascending)
+        const int wave = threadIdx.x >> 6;
+        const long long block_last = min(block_first + 256*PT, n) - 1;
+        const double x_lo = wavenumber_at(form, block_first)*kSpeedOfLight*100;
+        const double x_hi = wavenumber_at(form, block_last)*kSpeedOfLight*100;
+        for (int k0 = 0; k0 < set.n_bands; k0 += 2)
         {
-            const long long block_last = min(block_first + 256*PT, n) - 1;
-            const double x_lo = wavenumber_at(form, block_first)*kSpeedOfLight*100;
-            const double x_hi = wavenumber_at(form, block_last)*kSpeedOfLight*100;
-            lo = lower_bound(fgrid + b.offset, 0, b.size, x_lo);
-            hi = lower_bound(fgrid + b.offset, lo, b.size, x_hi);
+            const int k = k0 + (wave >> 1);
+            if (k < set.n_bands)
+            {
+                const XsecBand b = set.band[k];
+                const double * f = fgrid + b.offset;
+                // (a band none of this workgroup's points can lie in -- most bands for most
+                // workgroups -- gets the empty window and is skipped below without a search)
+                const bool touches = x_hi >= f[0] && x_lo <= f[b.size - 1];
+                const int found = touches ? wave_search<false>(f, 0, b.size, (wave & 1) ? x_hi : x_lo)
+                                          : -1;
+                if ((threadIdx.x & 63) == 0) window[k][wave & 1] = found;
+            }
         }
-        window[threadIdx.x][0] = lo;
-        window[threadIdx.x][1] = hi;
+    }
+    else if ((int)threadIdx.x < set.n_bands)
+    {
+        window[threadIdx.x][0] = 0;
+        window[threadIdx.x][1] = set.band[threadIdx.x].size;
     }
     double x[PT], total[PT][LV], before[PT][LV];
     load_wavenumbers<PT>(form, n, point_index, x);
@@ -182,11 +204,22 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
             before[p][l] = row[p];
         }
     }
-    __syncthreads();
     for (int k = 0; k < set.n_bands; ++k)
     {
         const XsecBand b = set.band[k];
         const double * f = fgrid + b.offset;
+        __syncthreads();        // window[] is set; the previous band's frequencies have been read
+        // The search reads f[w0 .. w1-1], the interval's lower knot may be f[w0-1].
+        const int w0 = window[k][0], w1 = window[k][1];
+        if (w0 < 0) continue;   // (the same for every thread of the workgroup)
+        const int base = max(w0 - 1, 0);
+        const int length = w1 - base;
+        const bool in_lds = length <= kXsecStage;
+        if (in_lds)
+        {
+            for (int t = threadIdx.x; t < length; t += blockDim.x) staged[t] = f[base + t];
+        }
+        __syncthreads();
         const double f_first = f[0], f_last = f[b.size - 1];
         int j[PT];
         double dx[PT];
@@ -201,22 +234,25 @@ __global__ __launch_bounds__(256) void xsec_interp_kernel(XsecSet set,
             {
                 // scipy interp1d (linear): searchsorted, clipped to [1, size-1]; the interval
                 // is (at-1, at).
-                at = lower_bound(f, window[k][0], window[k][1], x[p]);
+                at = in_lds ? base + lower_bound(staged, w0 - base, w1 - base, x[p])
+                            : lower_bound(f, w0, w1, x[p]);
                 at = at < 1 ? 1 : (at > b.size - 1 ? b.size - 1 : at);
             }
             j[p] = at - 1;
-            dx[p] = inside[p] ? x[p] - f[at - 1] : 0.;
+            const bool knot_staged = in_lds && at - 1 >= base && at - 1 < w1;
+            const double knot = !inside[p] ? 0. : (knot_staged ? staged[at - 1 - base] : f[at - 1]);
+            dx[p] = inside[p] ? x[p] - knot : 0.;
             any = any || inside[p];
         }
         if (__ballot(any) == 0ull) continue;
-        const long long base = (long long)level0*set.total + b.offset;
+        const long long table = (long long)level0*set.total + b.offset;
 #pragma unroll
         for (int p = 0; p < PT; ++p)
         {
 #pragma unroll
             for (int l = 0; l < LV; ++l)
             {
-                const long long at = base + (long long)(l < count ? l : 0)*set.total + j[p];
+                const long long at = table + (long long)(l < count ? l : 0)*set.total + j[p];
                 const double value = slopes[at]*dx[p] + values[at];
                 if (inside[p]) total[p][l] += value;
             }
