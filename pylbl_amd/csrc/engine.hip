@@ -207,6 +207,35 @@ int lbl_molecule_load(lbl_engine * engine, int64_t n_lines,
         std::vector<int> inverse((size_t)n_lines);
         for (long long j = 0; j < n_lines; ++j) inverse[m->order[j]] = (int)j;
         m->d_sorted_of_row.upload(inverse.data(), n_lines, stream);
+        // Where the sorted table reaches every eighth of a wavenumber (coarser for tables that
+        // span more than 131 072 cm-1): the bracket every search of the schedule starts from.
+        std::vector<int> cell_first;
+        if (n_lines > 0)
+        {
+            const std::vector<double> & sorted_nu = m->column[0];
+            const double base = std::floor(sorted_nu.front());
+            const double span = std::ceil(sorted_nu.back()) - base + 1.;
+            if (span >= 1. && span < 1.e12)
+            {
+                const double scale = std::min(8., std::floor(1048576./span*8.)/8.);
+                if (scale > 0.)
+                {
+                    const long long entries = (long long)(span*scale) + 1;
+                    cell_first.resize((size_t)entries);
+                    long long j = 0;
+                    for (long long i = 0; i < entries; ++i)
+                    {
+                        const double edge = base + (double)i/scale;
+                        while (j < n_lines && sorted_nu[(size_t)j] < edge) ++j;
+                        cell_first[(size_t)i] = (int)j;
+                    }
+                    m->cell_base = base;
+                    m->cell_scale = scale;
+                    m->cell_entries = (int)entries;
+                    m->d_cell_first.upload(cell_first.data(), cell_first.size(), stream);
+                }
+            }
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         // Reuse a freed slot if there is one.
         size_t slot = engine->molecules.size();

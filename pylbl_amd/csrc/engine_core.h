@@ -88,6 +88,11 @@ struct Molecule
     // Device copies (sorted).
     DeviceBuffer<double> d_column[7];
     DeviceBuffer<int> d_iso_slot, d_row, d_sorted_of_row;
+    // cell_first of LineTableView (tile_schedule.h): where the sorted table reaches every
+    // 1/cell_scale cm-1.
+    DeviceBuffer<int> d_cell_first;
+    double cell_base = 0., cell_scale = 0.;
+    int cell_entries = 0;
 
     // Work-item plans, one per (grid, cut_off, tiling) this molecule has been computed on.
     struct Plan
@@ -110,6 +115,8 @@ struct Molecule
         v.elower = d_column[5].data; v.delta_air = d_column[6].data;
         v.iso_slot = d_iso_slot.data; v.row = d_row.data;
         v.sorted_of_row = d_sorted_of_row.data; v.n_lines = n_lines;
+        v.cell_first = cell_entries > 0 ? d_cell_first.data : nullptr;
+        v.cell_base = cell_base; v.cell_scale = cell_scale; v.cell_entries = cell_entries;
         return v;
     }
 };
