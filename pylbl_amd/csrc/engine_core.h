@@ -610,12 +610,14 @@ struct lbl_engine
                 // (recorded behind this piece's accumulate launch)
                 HIP_TRY(hipStreamWaitEvent(f.finish_stream, lane.piece_summed[piece], 0));
             }
-            dim3 grid((unsigned)((q1 - q0 + 255)/256), (unsigned)f.count);
+            constexpr int per_block = 256*kApplyPoints;
+            dim3 grid((unsigned)((q1 - q0 + per_block - 1)/per_block), (unsigned)f.count);
             hipLaunchKernelGGL(pedestal_apply_kernel, grid, dim3(256),
-                               pedestal_apply_lds_bytes(f.cut_off), f.finish_stream, f.sums,
-                               f.sums_stride, f.target, f.target_stride,
+                               pedestal_apply_lds_bytes(f.cut_off, f.n_per_v), f.finish_stream,
+                               f.sums, f.sums_stride, f.target, f.target_stride,
                                lane.pedestal.bin_sum.data, lane.levels.data, (int)q0, (int)q1,
                                f.n_per_v, f.n_cells + 2*f.cut_off + 3, f.cut_off,
+                               pedestal_apply_span(f.n_per_v),
                                (f.flags & LBL_SCALE_DENSITY) ? 1 : 0, f.add_into ? 1 : 0);
             HIP_TRY(hipGetLastError());
             if (f.streamed && q0 < f.columns)

@@ -143,7 +143,10 @@ namespace lbl {
 // there).  Every workgroup forms the two totals of the (at most 256) cells its 256 points lie in
 // from the bins' totals, in LDS -- sums of non-negative totals in a fixed order: reproducible, and
 // exactly zero where no line reaches.  (Rounds 1-5 kept the two tables in HBM, written by a
-// launch of their own.)
+// launch of their own.)  Four points per thread: the kernel moves 16-24 bytes per point and
+// nothing else, and one point per thread left it at a third of what HBM gives.
+constexpr int kApplyPoints = 4;     // grid points per thread of pedestal_apply_kernel
+
 __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __restrict__ sums,
                                                              long long sums_stride,
                                                              double * __restrict__ out,
@@ -151,50 +154,72 @@ __global__ __launch_bounds__(256) void pedestal_apply_kernel(const double * __re
                                                              const double * __restrict__ bin_sum,
                                                              const LevelScalars * __restrict__ levels,
                                                              int first, int end, int n_per_v,
-                                                             int n_bins, int cut_off,
+                                                             int n_bins, int cut_off, int max_span,
                                                              int scale_density, int accumulate)
 {
-    // Points [first, end): the whole grid, or the columns of one piece of a streamed call.
+    // Points [first, end): the whole grid, or the columns of one piece of a streamed call; a
+    // workgroup takes 256 x kApplyPoints consecutive ones (thread t: t, t + 256, ...).
     extern __shared__ double apply_lds[];
+    constexpr int kBlock = 256*kApplyPoints;
     const int level = blockIdx.y;
-    const int i_lo = first + blockIdx.x*256;
+    const int i_lo = first + blockIdx.x*kBlock;
     if (i_lo >= end) return;
-    const int i_hi = min(i_lo + 255, end - 1);
+    const int i_hi = min(i_lo + kBlock - 1, end - 1);
     const int cell_lo = i_lo/n_per_v;
-    const int span = i_hi/n_per_v - cell_lo + 1;            // <= 256 cells
+    const int span = i_hi/n_per_v - cell_lo + 1;            // <= max_span cells
     const int wanted = span + 2*cut_off + 1;                // bins cell_lo .. cell_hi + 2 cut_off + 1
     double * bins = apply_lds;
-    double * cell_sum = apply_lds + 256 + 2*cut_off + 2;
-    double * point_sum = cell_sum + 256;
+    double * cell_sum = apply_lds + max_span + 2*cut_off + 2;
+    double * point_sum = cell_sum + max_span;
     const double * source = bin_sum + (long long)level*n_bins + cell_lo;
     for (int t = threadIdx.x; t < wanted; t += 256) bins[t] = source[t];
     __syncthreads();
-    if ((int)threadIdx.x < span)
+    for (int c = threadIdx.x; c < span; c += 256)
     {
         double interior = 0.;
         for (int k = 1; k <= 2*cut_off + 1; ++k)
         {
-            interior += bins[threadIdx.x + k];
+            interior += bins[c + k];
         }
-        cell_sum[threadIdx.x] = interior;
-        point_sum[threadIdx.x] = interior + bins[threadIdx.x];
+        cell_sum[c] = interior;
+        point_sum[c] = interior + bins[c];
     }
     __syncthreads();
-    const int i = i_lo + threadIdx.x;
-    if (i >= end) return;
-    const int cell = i/n_per_v;
-    const bool on_integer = (cell*n_per_v == i);
-    const double pedestal = on_integer ? point_sum[cell - cell_lo] : cell_sum[cell - cell_lo];
-    double value = sums[(long long)level*sums_stride + i] - pedestal;
-    if (scale_density) value *= levels[level].density;
+    const double density = scale_density ? levels[level].density : 1.;
+    const double * from = sums + (long long)level*sums_stride;
     double * k = out + (long long)level*out_stride;
-    if (accumulate) value += k[i];
-    k[i] = value;
+    double value[kApplyPoints], before[kApplyPoints];
+#pragma unroll
+    for (int j = 0; j < kApplyPoints; ++j)
+    {
+        const int i = i_lo + (int)threadIdx.x + 256*j;
+        value[j] = i < end ? from[i] : 0.;
+        before[j] = (accumulate && i < end) ? k[i] : 0.;
+    }
+#pragma unroll
+    for (int j = 0; j < kApplyPoints; ++j)
+    {
+        const int i = i_lo + (int)threadIdx.x + 256*j;
+        if (i >= end) continue;
+        const int cell = i/n_per_v;
+        const bool on_integer = (cell*n_per_v == i);
+        const double pedestal = on_integer ? point_sum[cell - cell_lo] : cell_sum[cell - cell_lo];
+        double result = value[j] - pedestal;
+        if (scale_density) result *= density;
+        if (accumulate) result += before[j];
+        k[i] = result;
+    }
 }
 
-inline size_t pedestal_apply_lds_bytes(int cut_off)
+// Cells a workgroup's points can lie in, and the dynamic LDS the kernel asks for.
+inline int pedestal_apply_span(int n_per_v)
 {
-    return (size_t)(256 + 2*cut_off + 2 + 512)*sizeof(double);
+    return 256*kApplyPoints/std::max(n_per_v, 1) + 2;
+}
+
+inline size_t pedestal_apply_lds_bytes(int cut_off, int n_per_v)
+{
+    return (size_t)(3*pedestal_apply_span(n_per_v) + 2*cut_off + 2)*sizeof(double);
 }
 
 // The pedestal pre-pass for `count` levels whose LineWing/LineCore arrays are already in
