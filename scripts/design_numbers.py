@@ -1,6 +1,6 @@
 """Prints the results table of DESIGN.md section 8 from profiles/bench_<tag>*_full.json (the whole
 records scripts/bench_round.sh writes beside the short lines).  Build container:
-python scripts/design_numbers.py r06a"""
+python scripts/design_numbers.py r06b"""
 import json
 import sys
 
@@ -74,7 +74,7 @@ out.append("| slot 1: H2O foreign + self + CO2 continua in one pass, 5 M points 
                c["roofline"]["frac"], (c["roofline"].get("traffic") or 0)/1e6,
                c["one_launch_per_continuum"]["ms_per_step"]))
 out.append("| slot 2: one two-band cross-section molecule | %.3g pts/s | %.3f | %.0f | interp %.1f µs: "
-           "%.2f of HBM (binary search: latency-bound) |" % (
+           "%.2f of HBM (searches in LDS, one wavefront per band window) |" % (
                x["value"], x["ms_per_step"], x["spectra_per_s"], x["kernel_ms_per_step"]["interpolate"]*1e3,
                x["roofline"]["frac"]))
 a = d["api_call"]["formats"]
