@@ -83,7 +83,18 @@ __device__ __forceinline__ void series_terms(const LineWing * __restrict__ w, in
         }
     };
     int at = first;
-    for (; at + THREADS < end; at += 2*THREADS)     // two loads in flight
+    for (; at + 3*THREADS < end; at += 4*THREADS)   // four loads in flight
+    {
+        const LineWing l0 = w[line_at(at)];
+        const LineWing l1 = w[line_at(at + THREADS)];
+        const LineWing l2 = w[line_at(at + 2*THREADS)];
+        const LineWing l3 = w[line_at(at + 3*THREADS)];
+        add_line(l0);
+        add_line(l1);
+        add_line(l2);
+        add_line(l3);
+    }
+    for (; at + THREADS < end; at += 2*THREADS)
     {
         const LineWing l0 = w[line_at(at)];
         const LineWing l1 = w[line_at(at + THREADS)];
