@@ -397,21 +397,25 @@ __device__ __forceinline__ void core_line(const LineWing & l, const LineCore & c
     const double d0 = a0*a0;
     const double d2 = yq + yq - 1.;
     const double r1_scale = c.amp*rsqrpi*c.y;
+    // (rows that are neither: the far wing -- most rows of most lines, so that is the path the
+    // wavefront falls through to: a taken branch costs it its instruction buffer, and the chain
+    // "region 1? / near the core? / else" took two per far-wing row)
+    const unsigned special = rows | (rows >> 8);
 #pragma unroll
     for (int p = 0; p < P; ++p)
     {
         const double d = v[p] - l.centre;
-        if (rows & (1u << p))
+        if (__builtin_expect(!(special & (1u << p)), 1))
+        {
+            // voigt.c:82 / :24 in wavenumber units: the whole row is in the far wing.
+            acc[p] = __builtin_fma(l.bl, rcp_newton(__builtin_fma(d, d, l.g2)), acc[p]);
+        }
+        else if (rows & (1u << p))
         {
             // voigt.c:95-96 with no selection left to make.
             const double xi = d*c.repwid;
             const double xq = xi*xi;
             acc[p] += r1_scale*(a0 + xq)*rcp_newton(__builtin_fma(xq, d2 + xq, d0));
-        }
-        else if (!(rows & (256u << p)))
-        {
-            // voigt.c:82 / :24 in wavenumber units: the whole row is in the far wing.
-            acc[p] = __builtin_fma(l.bl, rcp_newton(__builtin_fma(d, d, l.g2)), acc[p]);
         }
         else
         {
