@@ -76,8 +76,10 @@ def issue_slot_fraction(issue, launch_ms):
            "frac_of_issue_slots_at_2.4GHz": rate/(SIMDS*BOOST_CLOCK_GHZ*1e9/4.),
            "kernel": issue.get("kernel"), "source": issue.get("source")}
     if issue.get("sclk_ghz_measured"):
-        out["sclk_ghz_measured"] = issue["sclk_ghz_measured"]
-        out["frac_of_issue_slots_at_measured_clock"] = \
-            rate/(SIMDS*issue["sclk_ghz_measured"]*1e9/4.)
+        # (GRBM_GUI_ACTIVE over the launch's own duration; for a short launch that ran beside
+        # another the quotient can come out above what the chip can clock: never more than boost)
+        clock = min(issue["sclk_ghz_measured"], BOOST_CLOCK_GHZ)
+        out["sclk_ghz_measured"] = clock
+        out["frac_of_issue_slots_at_measured_clock"] = rate/(SIMDS*clock*1e9/4.)
     return out
 

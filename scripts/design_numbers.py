@@ -1,6 +1,6 @@
 """Prints the results table of DESIGN.md section 8 from profiles/bench_<tag>*_full.json (the whole
 records scripts/bench_round.sh writes beside the short lines).  Build container:
-python scripts/design_numbers.py r06c"""
+python scripts/design_numbers.py r06d"""
 import json
 import sys
 
