@@ -1,8 +1,8 @@
 // Pedestal removal, second part: the recurrence over the runs in reference row order
-// (spectra.c:66-78 taken run by run) -- run_prefix / run_links (which earlier runs hold a run's end
-// slots, and what they added there), run_relax (the recurrence as a triangular system, a few
-// launches) and run_chain (the serial form, for the levels the relaxation leaves).  Included by
-// pedestal.h after pedestal_runs.h.
+// (spectra.c:66-78 taken run by run) -- run_links (which earlier runs hold a run's end slots, and
+// what they added there), run_solve (the recurrence as a triangular system: a few sweeps inside one
+// launch) and run_chain (the serial form, for the levels the sweeps leave; run by the chunk that
+// leaves run_solve last).  Included by pedestal.h after pedestal_runs.h.
 #pragma once
 
 namespace lbl {
@@ -24,12 +24,12 @@ namespace lbl {
 // neighbour's where pressure shifts make two windows alternate, has added to it -- so such a run
 // does not look at history at all.  On every line table tried (uniform, banded, sparse:
 // profiles/r04_pedestal_branches.txt) that is all but a handful of runs, and chains are 2-4 runs
-// long.  run_relax_kernel: one wavefront per 64 consecutive runs (lane = run), the chunk solved
-// exactly by forward substitution, earlier chunks' values taken from the previous launch.  The
-// second and later launches report whether anything changed, and a launch that changed nothing
+// long.  run_solve_kernel: one wavefront per 64 consecutive runs (lane = run), the chunk solved
+// exactly by forward substitution, earlier chunks' values taken from their previous sweep.  The
+// second and later sweeps report whether anything changed, and a sweep that changed nothing
 // has verified a fixed point, i.e. the solution a serial evaluation of the same formula gives, bit
 // for bit and independent of how it was reached.  Levels that have not settled after the last
-// launch keep run_chain_kernel.  ~25 us for the 400 k-line benchmark table, where the serial
+// sweep get the serial chain.  ~25 us for the 400 k-line benchmark table, where the serial
 // forms take a wavefront 0.2-0.75 ms: one wavefront issues an instruction every fourth cycle at
 // best, and 5 300 dependent steps of ~100 instructions are 2 M cycles however they are arranged.
 //
@@ -43,7 +43,7 @@ namespace lbl {
 // benchmark's tables, 1 800 where a 4 M-line table has 800 lines to the wavenumber and dozens of
 // them alternate between two windows at every integer -- nothing is out of sight.  (The first form
 // of this kept bit masks over the previous 256 runs and gave up beyond.)  What still costs
-// launches is a chain that matters ACROSS chunks: one launch per boundary it crosses.
+// sweeps is a chain that matters ACROSS chunks: one sweep per boundary it crosses.
 // ---------------------------------------------------------------------------------------
 // Per level (kChainState ints, reset by run_find_kernel): [0] 1 while the relaxation applies
 // (cleared by run_links_kernel where rows are too far out of order, by the first sweep where one

@@ -1,7 +1,7 @@
-// Pedestal removal, first part: the runs of rows with one window (run_count / run_offset /
-// run_compact: a three-pass scan in reference row order) and their profile sums on the window's
-// slots (run_sums: one wavefront per run).  The factorisation is stated in pedestal.h, which
-// includes this file after the workspace types; spectra.c:66-78 is the reference.
+// Pedestal removal, first part: the runs of rows with one window (run_find: one single-pass scan
+// in reference row order, with the running maximum of the runs' bins) and their profile sums on the
+// window's slots (run_sums: one wavefront per run).  The factorisation is stated in pedestal.h,
+// which includes this file after the workspace types; spectra.c:66-78 is the reference.
 #pragma once
 
 namespace lbl {
