@@ -430,6 +430,58 @@ def test_bench_reads_the_newest_profile_by_its_round_tag():
     assert issue["source"] == "profiles/" + counters[-1]
 
 
+def test_bench_short_line_fits_the_drivers_tail_also_for_eight_ranks():
+    """benchlegs.compact: the ONE line bench.py prints is an extract of the whole record -- the
+    contract's keys untouched, roofline / cpu_baseline without prose, one short record per leg --
+    and stays far below the 8 KB of stdout the driver keeps, also when eight ranks report."""
+    import copy
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from benchlegs import compact
+    records = sorted((ROOT / "profiles").glob("bench_r??[a-z]_full.json"), key=lambda p: p.name)
+    if not records:
+        pytest.skip("no whole bench record under profiles/")
+    full = json.loads(records[-1].read_text())
+    line = compact.compact(full, full_record="bench_full.json")
+    text = json.dumps(line)
+    assert len(text) <= compact.TARGET_BYTES < compact.LIMIT_BYTES
+    for key in compact.CONTRACT:
+        assert line[key] == full[key], key
+    assert line["config"]["workload"] == full["config"]["workload"] and "model" not in line["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+            "launches_timed", "evals_per_launch"} <= set(line["roofline"])
+    assert not any(isinstance(v, str) and len(v) > 40 for v in line["roofline"].values())
+    assert {"value", "unit", "cores", "kind", "sample", "cpu", "host_cores"} <= set(line["cpu_baseline"])
+    assert {"pedestal", "config0", "config1", "config2", "config3_share", "config4_share",
+            "farfield_plain", "farfield_pedestal", "api_call", "continuum", "xsec",
+            "ingest_s"} <= set(line["legs"])
+    issue = line["roofline"]["issue"]
+    assert abs(issue["evals_per_launch"] - line["roofline"]["evals_per_launch"]) \
+        <= 1e-3*line["roofline"]["evals_per_launch"]
+    assert 0. < issue["frac_of_issue_ceiling_at_2.4GHz"] <= 1.
+    # Eight ranks (what the driver's scaling run prints): per-rank spectra/s and exchange waits on
+    # the short line, device identities only in the whole record.
+    eight = copy.deepcopy(full)
+    eight["n_gpus"] = 8
+    eight["distributed"] = {
+        "world_size": 8, "backend": "nccl", "launcher": "torch.distributed.run",
+        "distinct_devices": 8, "ranks_sharing_a_device": {},
+        "kernels_to_exchange_ordering": "device (events between the engine's streams and the "
+                                        "exchange's, no host wait)",
+        "bytes_to_rank0_per_step": 7*80000000, "exchange_alone_ms_max": 3.2,
+        "ranks": [{"rank": r, "device_index": r, "name": "AMD Instinct MI355X", "uuid": "x"*36,
+                   "ms_per_step": 4.2 + 0.01*r, "spectra_per_s": 238.1, "evals_per_step": 25947343421,
+                   "exchange_wait_ms_per_step": 0.02*r, "bytes_sent_per_step": 80000000,
+                   "unoverlapped_exchange_ms": 3.1} for r in range(8)]}
+    line8 = compact.compact(eight, full_record="bench_full.json")
+    assert len(json.dumps(line8)) <= compact.TARGET_BYTES
+    assert [r["rank"] for r in line8["distributed"]["ranks"]] == list(range(8))
+    assert all({"spectra_per_s", "exchange_wait_ms_per_step"} <= set(r)
+               for r in line8["distributed"]["ranks"])
+    assert "uuid" not in line8["distributed"]["ranks"][0]
+
+
 def test_banded_tables_inside_the_grid_drop_what_falls_outside():
     a = synthetic.banded_line_table("CO2", 1., 5000., num_lines=20000, bands=8, seed=5)
     b = synthetic.banded_line_table("CO2", 1., 5000., num_lines=20000, bands=8, seed=5, inside=True)
